@@ -1,0 +1,112 @@
+"""ctypes binding of libaoc_hip.so (C-ABI declared in include/aoc.h).
+
+There is no CPU fallback: if the shared library has not been built, or no GPU is visible when a
+compute entry point is called, an AocError is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_PKG, "lib", "libaoc_hip.so")
+_SRC = [os.path.join(_PKG, "csrc", f) for f in ("aoc_kernels.hip", "aoc_device.h")]
+_HDR = os.path.join(os.path.dirname(_PKG), "include", "aoc.h")
+
+AOC_TILE = 64
+
+# status flags (include/aoc.h)
+ST_NAN, ST_VNONPOS, ST_SINGULAR, ST_REGULARISED, ST_ARMIJO_EXH, ST_CONVERGED = 1, 2, 4, 8, 16, 32
+
+
+class AocError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    deps = _SRC + [_HDR]
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(d) for d in deps):
+        return _SO
+    os.makedirs(os.path.dirname(_SO), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", _SRC[0], "-o", _SO]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _SO
+
+
+class Model(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("cd0", "cda", "cla", "m", "g", "S", "rho", "J", "dt")]
+
+
+class Problem(C.Structure):
+    _fields_ = [("model", Model), ("QQt", C.c_double * 36), ("RRt", C.c_double * 4), ("QQT", C.c_double * 36),
+                ("B", C.c_int32), ("T", C.c_int32), ("ref", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class Params(C.Structure):
+    _fields_ = [("max_iters", C.c_int32), ("armijo_maxiters", C.c_int32), ("stepsize_0", C.c_double),
+                ("cc", C.c_double), ("beta", C.c_double), ("term_cond", C.c_double),
+                ("hessian_switch", C.c_int32), ("reserved", C.c_int32)]
+
+
+# every symbol include/aoc.h declares: (name, restype, argtypes)
+_P, _I, _D, _Z = C.c_void_p, C.c_int32, C.c_double, C.c_size_t
+SYMBOLS = {
+    "aoc_version": (C.c_char_p, []),
+    "aoc_strerror": (C.c_char_p, [C.c_int]),
+    "aoc_last_hip_error": (C.c_char_p, []),
+    "aoc_tiled_elems": (_Z, [_I, _I, _I]),
+    "aoc_ntiles": (_I, [_I]),
+    "aoc_pack": (C.c_int, [_I, _I, _I, _P, _P, _P]),
+    "aoc_unpack": (C.c_int, [_I, _I, _I, _P, _P, _P]),
+    "aoc_step_batch": (C.c_int, [_P, _I] + [_P] * 10),
+    "aoc_cost_batch": (C.c_int, [_P, _I] + [_P] * 10),
+    "aoc_traj_cost": (C.c_int, [_P, _P, _P, _P]),
+    "aoc_rollout_cost": (C.c_int, [_P] * 9),
+    "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
+    "aoc_forward": (C.c_int, [_P, _D] + [_P] * 11),
+    "aoc_linesearch": (C.c_int, [_P] * 13),
+    "aoc_workspace_bytes": (_Z, [_I, _I]),
+    "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 12),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded C library.  Raises AocError (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise AocError("libaoc_hip.so is not built (%s). Run __graft_entry__.build() or "
+                           "aircraftoptimalcontrol_amd.build_library(); there is no CPU fallback." % _SO)
+        try:
+            l = C.CDLL(_SO)
+        except OSError as e:  # e.g. ROCm runtime missing
+            raise AocError("cannot load %s: %s" % (_SO, e))
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        l = lib()
+        raise AocError("%s failed: %s (%s)" % (what or "aoc call", l.aoc_strerror(rc).decode(),
+                                                l.aoc_last_hip_error().decode()))
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise AocError("no GPU visible: the aoc HIP path has no CPU fallback")
+    return torch

@@ -1,0 +1,368 @@
+"""Batched host API over the C-ABI (include/aoc.h).
+
+torch-ROCm is used for device memory, streams and (in bench.py) torch.distributed only; every
+numerical operation of the hot path is a HIP kernel of libaoc_hip.so.  Arrays at this level use the
+reference's per-trajectory conventions stacked over the batch: xx (B,6,T), uu (B,2,T), float64.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import AocError, Model, Params, Problem, check, lib
+
+TILE = _lib.AOC_TILE
+
+
+def default_model(dt=1e-3):
+    """Dynamics.__init__ constants (reference aircraft_simplified.py:108-118)."""
+    return Model(0.1716, 2.395, 3.256, 12.0, 9.81, 0.61, 1.2, 0.24, dt)
+
+
+def make_params(max_iters=200, stepsize_0=1e-2, cc=0.5, beta=0.7, armijo_maxiters=20, term_cond=-1e-6,
+                hessian_switch=8):
+    """NewtonMethod constructor defaults (reference optcon.py:335-339); term_cond is the value the
+    reference hard-codes (-1e-6, optcon.py:368), not the ignored constructor argument."""
+    return Params(int(max_iters), int(armijo_maxiters), float(stepsize_0), float(cc), float(beta),
+                  float(term_cond), int(hessian_switch), 0)
+
+
+def _torch():
+    return _lib.require_gpu()
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev_f64(a, device):
+    torch = _torch()
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=torch.float64).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+
+
+class BatchProblem:
+    """Dynamics constants + Cost weights + reference curves on one GPU.
+
+    Mirrors what NewtonMethod.__init__ captures (reference optcon.py:335-339): the reference curves
+    are shared by every trajectory of the batch."""
+
+    def __init__(self, QQt, RRt, QQT, xx_ref, uu_ref, dt, model=None, device="cuda:0"):
+        torch = _torch()
+        self.device = torch.device(device)
+        xx_ref = np.ascontiguousarray(xx_ref, dtype=np.float64)
+        uu_ref = np.ascontiguousarray(uu_ref, dtype=np.float64)
+        if xx_ref.ndim != 2 or xx_ref.shape[0] != 6 or uu_ref.shape != (2, xx_ref.shape[1]):
+            raise ValueError("xx_ref must be (6,T) and uu_ref (2,T)")
+        self.T = int(xx_ref.shape[1])
+        self.QQt = np.ascontiguousarray(QQt, dtype=np.float64).reshape(6, 6)
+        self.RRt = np.ascontiguousarray(RRt, dtype=np.float64).reshape(2, 2)
+        self.QQT = np.ascontiguousarray(QQT, dtype=np.float64).reshape(6, 6)
+        self.model = model if model is not None else default_model(dt)
+        self.model.dt = float(dt)
+        self.xx_ref, self.uu_ref = xx_ref, uu_ref
+        ref = np.concatenate([xx_ref, uu_ref], axis=0).T.copy()  # [T][8]
+        self.ref = torch.from_numpy(ref).to(self.device)
+
+    def c_problem(self, B, stream=None):
+        torch = _torch()
+        p = Problem()
+        p.model = self.model
+        p.QQt[:] = self.QQt.ravel().tolist()
+        p.RRt[:] = self.RRt.ravel().tolist()
+        p.QQT[:] = self.QQT.ravel().tolist()
+        p.B, p.T = int(B), self.T
+        p.ref = self.ref.data_ptr()
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        p.stream = s.cuda_stream
+        return p
+
+
+def ntiles(B):
+    return (B + TILE - 1) // TILE
+
+
+def alloc_tiled(B, T, Cc, device, zero=False):
+    torch = _torch()
+    shape = (ntiles(B), T, Cc, TILE)
+    return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float64, device=device)
+
+
+def pack(a_bct, device=None):
+    """(B,C,T) -> tiled [ntiles][T][C][64] on the device (aoc_pack)."""
+    torch = _torch()
+    if device is None:
+        device = a_bct.device if isinstance(a_bct, torch.Tensor) and a_bct.is_cuda else "cuda:0"
+    src = _dev_f64(a_bct, device)
+    B, Cc, T = src.shape
+    dst = alloc_tiled(B, T, Cc, src.device)
+    check(lib().aoc_pack(B, T, Cc, _ptr(src), _ptr(dst), C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)),
+          "aoc_pack")
+    return dst
+
+
+def unpack(tiled, B):
+    """tiled -> (B,C,T) torch tensor on the device (aoc_unpack)."""
+    torch = _torch()
+    nt, T, Cc, _ = tiled.shape
+    dst = torch.empty((B, Cc, T), dtype=torch.float64, device=tiled.device)
+    check(lib().aoc_unpack(B, T, Cc, _ptr(tiled), _ptr(dst),
+                           C.c_void_p(torch.cuda.current_stream(tiled.device).cuda_stream)), "aoc_unpack")
+    return dst
+
+
+def pack_vec(a_bc, device):
+    """(B,C) per-trajectory vectors -> [ntiles][C][64]."""
+    torch = _torch()
+    a = _dev_f64(a_bc, device)
+    B, Cc = a.shape
+    nt = ntiles(B)
+    if nt * TILE != B:
+        a = torch.cat([a, a[-1:].expand(nt * TILE - B, Cc)], 0)
+    return a.reshape(nt, TILE, Cc).permute(0, 2, 1).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# unit level
+# ------------------------------------------------------------------------------------------------
+def step_batch(model, x, u, lmbd=None, device="cuda:0"):
+    """Dynamics.step for n points (reference aircraft_simplified.py:263-393).
+    Returns numpy (xp, fx, fu, fxx, fuu, fux); the last three are None without lmbd."""
+    torch = _torch()
+    xd, ud = _dev_f64(np.atleast_2d(x), device), _dev_f64(np.atleast_2d(u), device)
+    n = xd.shape[0]
+    ld = None if lmbd is None else _dev_f64(np.atleast_2d(lmbd), device)
+    mk = lambda *s: torch.empty(s, dtype=torch.float64, device=xd.device)
+    xp, fx, fu = mk(n, 6), mk(n, 6, 6), mk(n, 2, 6)
+    fxx, fuu, fux = (mk(n, 6, 6), mk(n, 2, 2), mk(n, 2, 6)) if ld is not None else (None, None, None)
+    st = C.c_void_p(torch.cuda.current_stream(xd.device).cuda_stream)
+    check(lib().aoc_step_batch(C.byref(model), n, _ptr(xd), _ptr(ud), _ptr(ld), _ptr(xp), _ptr(fx), _ptr(fu),
+                               _ptr(fxx), _ptr(fuu), _ptr(fux), st), "aoc_step_batch")
+    torch.cuda.synchronize(xd.device)
+    out = [xp, fx, fu, fxx, fuu, fux]
+    return tuple(None if o is None else o.cpu().numpy() for o in out)
+
+
+def cost_batch(problem, x, u, xr, ur):
+    """Cost.stagecost/termcost for n points (reference aircraft_simplified.py:25-97).
+    Returns numpy (ll, lx, lu, llT, lTx)."""
+    torch = _torch()
+    dev = problem.device
+    xd, ud, xrd, urd = (_dev_f64(np.atleast_2d(a), dev) for a in (x, u, xr, ur))
+    n = xd.shape[0]
+    mk = lambda *s: torch.empty(s, dtype=torch.float64, device=dev)
+    ll, lx, lu, llT, lTx = mk(n), mk(n, 6), mk(n, 2), mk(n), mk(n, 6)
+    p = problem.c_problem(n)
+    check(lib().aoc_cost_batch(C.byref(p), n, _ptr(xd), _ptr(ud), _ptr(xrd), _ptr(urd), _ptr(ll), _ptr(lx), _ptr(lu),
+                               _ptr(llT), _ptr(lTx), C.c_void_p(p.stream)), "aoc_cost_batch")
+    torch.cuda.synchronize(dev)
+    return tuple(o.cpu().numpy() for o in (ll, lx, lu, llT, lTx))
+
+
+# ------------------------------------------------------------------------------------------------
+# iteration level
+# ------------------------------------------------------------------------------------------------
+class NewtonBatchSolver:
+    """B independent NewtonMethod.optimize instances (reference optcon.py:341-529) on one GPU.
+
+    Device state (all tiled, fp64): three (x,u) iterate buffers in rotation, K~/g/du workspace,
+    per-trajectory scalars.  `iterate(kk)` = one outer iteration for every trajectory;
+    `solve()` adds the reference's termination and return-index behaviour per trajectory."""
+
+    def __init__(self, problem, B, params=None):
+        torch = _torch()
+        self.problem, self.B, self.T = problem, int(B), problem.T
+        self.params = params if params is not None else make_params()
+        dev = problem.device
+        self.nt = ntiles(self.B)
+        self.Bp = self.nt * TILE
+        self.xb = [alloc_tiled(B, self.T, 6, dev, zero=True) for _ in range(3)]
+        self.ub = [alloc_tiled(B, self.T, 2, dev, zero=True) for _ in range(3)]
+        self.ws = torch.empty(lib().aoc_workspace_bytes(self.B, self.T) // 8, dtype=torch.float64, device=dev)
+        f = lambda: torch.zeros(self.Bp, dtype=torch.float64, device=dev)
+        self.J = [f(), f()]
+        self.descent, self.stepsize = f(), f()
+        self.ntrials = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
+        self.x0 = torch.zeros((self.nt, 6, TILE), dtype=torch.float64, device=dev)
+        self.cur = 0      # index of the buffer holding the current iterate
+        self.kk = 0       # outer-iteration index of the current iterate
+        self.jcur = 0
+
+    # -- problem struct with the current stream
+    def _p(self):
+        return self.problem.c_problem(self.B)
+
+    def set_initial(self, xx_init, uu_init):
+        """xx[:,:,0], uu[:,:,0] = xx_init, uu_init; x0 = xx_init[:,0] (reference optcon.py:395-398)."""
+        torch = _torch()
+        dev = self.problem.device
+        xi, ui = _dev_f64(xx_init, dev), _dev_f64(uu_init, dev)
+        if tuple(xi.shape) != (self.B, 6, self.T) or tuple(ui.shape) != (self.B, 2, self.T):
+            raise ValueError("xx_init must be (B,6,T)=(%d,6,%d) and uu_init (B,2,T)" % (self.B, self.T))
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        check(lib().aoc_pack(self.B, self.T, 6, _ptr(xi), _ptr(self.xb[0]), st), "aoc_pack")
+        check(lib().aoc_pack(self.B, self.T, 2, _ptr(ui), _ptr(self.ub[0]), st), "aoc_pack")
+        self.x0.copy_(self.xb[0][:, 0, :, :])
+        self.cur, self.kk, self.jcur = 0, 0, 0
+        self.status.zero_()
+        p = self._p()
+        check(lib().aoc_traj_cost(C.byref(p), _ptr(self.xb[0]), _ptr(self.ub[0]), _ptr(self.J[0])), "aoc_traj_cost")
+
+    def iterate(self, kk=None):
+        """One outer iteration (steps A-G of SURVEY 3.2) for every trajectory; asynchronous."""
+        if kk is None:
+            kk = self.kk
+        p = self._p()
+        c, n = self.cur, (self.cur + 1) % 3
+        jc, jn = self.jcur, 1 - self.jcur
+        check(lib().aoc_newton_iterate(C.byref(p), C.byref(self.params), int(kk), _ptr(self.xb[c]), _ptr(self.ub[c]),
+                                       _ptr(self.x0), _ptr(self.J[jc]), _ptr(self.ws), _ptr(self.xb[n]),
+                                       _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.descent), _ptr(self.stepsize),
+                                       _ptr(self.ntrials), _ptr(self.status)), "aoc_newton_iterate")
+        self.cur, self.jcur, self.kk = n, jn, kk + 1
+
+    # -- results ---------------------------------------------------------------------------------
+    def current(self, which=0):
+        """Current iterate (which=0), previous (-1) or the one before (-2) as numpy (B,6,T),(B,2,T)."""
+        i = (self.cur + which) % 3
+        return unpack(self.xb[i], self.B).cpu().numpy(), unpack(self.ub[i], self.B).cpu().numpy()
+
+    def scalars(self):
+        """Per-trajectory scalars of the LAST iteration: cost of the iterate it started from, descent,
+        accepted step, number of Armijo trials, cost of the new iterate, status flags."""
+        B = self.B
+        return dict(cost=self.J[1 - self.jcur][:B].cpu().numpy(), descent=self.descent[:B].cpu().numpy(),
+                    stepsize=self.stepsize[:B].cpu().numpy(), ntrials=self.ntrials[:B].cpu().numpy(),
+                    cost_new=self.J[self.jcur][:B].cpu().numpy(), status=self.status[:B].cpu().numpy())
+
+    def run_fixed(self, n_iters, kk0=None, record=True):
+        """n_iters iterations for every trajectory, no early exit (the bench mode)."""
+        hist = []
+        if kk0 is not None:
+            self.kk = kk0
+        for _ in range(n_iters):
+            self.iterate()
+            if record:
+                hist.append(self.scalars())
+        return hist
+
+    def solve(self, verbose=False):
+        """NewtonMethod.optimize semantics per trajectory (reference optcon.py:415-505):
+        iterate kk = 0..max_iters-2; a trajectory stops at the first kk with descent >= term_cond and
+        then returns iterate kk-1 (python index -1 = an all-zero history slot when kk == 0); without
+        convergence it returns the last computed iterate; finally uu_star[:,-1] = uu_star[:,-2].
+        Returns dict(xx_star (B,6,T), uu_star (B,2,T), iters (B,), history lists)."""
+        torch = _torch()
+        B, prm = self.B, self.params
+        dev = self.problem.device
+        active = torch.ones(self.Bp, dtype=torch.bool, device=dev)
+        iters = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
+        res_x = torch.zeros_like(self.xb[0])
+        res_u = torch.zeros_like(self.ub[0])
+        hist = dict(cost=[], descent=[], stepsize=[], ntrials=[])
+        last = -1
+        for kk in range(prm.max_iters - 1):
+            self.iterate(kk)
+            last = kk
+            for k_, v in self.scalars().items():
+                if k_ in hist:
+                    hist[k_].append(v)
+            conv = active & (self.descent >= prm.term_cond)
+            iters = torch.where(active, torch.full_like(iters, kk + 1), iters)
+            if bool(conv.any()):
+                m = conv.reshape(self.nt, 1, 1, TILE)
+                if kk >= 1:  # iterate kk-1 lives two buffers behind the newest
+                    res_x = torch.where(m, self.xb[(self.cur + 1) % 3], res_x)
+                    res_u = torch.where(m, self.ub[(self.cur + 1) % 3], res_u)
+                # kk == 0: xx[:,:,-1] is the untouched, all-zero last history slot
+                self.status |= conv.to(torch.int32) * _lib.ST_CONVERGED
+                active = active & ~conv
+            if verbose:
+                s = self.scalars()
+                print("Iter = %d\t Descent = %r\t Cost = %r\t active = %d" %
+                      (kk, float(s["descent"][0]), float(s["cost"][0]), int(active[:B].sum())))
+            if not bool(active[:B].any()):
+                break
+        # trajectories that never converged return the last computed iterate (index max_iters-1)
+        m = active.reshape(self.nt, 1, 1, TILE)
+        res_x = torch.where(m, self.xb[self.cur], res_x)
+        res_u = torch.where(m, self.ub[self.cur], res_u)
+        xs = unpack(res_x, B)
+        us = unpack(res_u, B)
+        us[:, :, -1] = us[:, :, -2]  # optcon.py:505
+        return dict(xx_star=xs.cpu().numpy(), uu_star=us.cpu().numpy(), iters=iters[:B].cpu().numpy(),
+                    converged=(~active[:B]).cpu().numpy(), status=self.status[:B].cpu().numpy(),
+                    history={k_: np.stack(v, 1) if v else np.zeros((B, 0)) for k_, v in hist.items()},
+                    last_kk=last)
+
+
+# ------------------------------------------------------------------------------------------------
+# pass level (thin functional wrappers used by the drop-in modules and the parity tests)
+# ------------------------------------------------------------------------------------------------
+def traj_cost(problem, xx, uu):
+    """Cost of stored trajectories (reference optcon.py:417-424).  xx (B,6,T), uu (B,2,T) -> (B,)"""
+    torch = _torch()
+    xt, ut = pack(xx, problem.device), pack(uu, problem.device)
+    B = xx.shape[0]
+    J = torch.empty(ntiles(B) * TILE, dtype=torch.float64, device=problem.device)
+    p = problem.c_problem(B)
+    check(lib().aoc_traj_cost(C.byref(p), _ptr(xt), _ptr(ut), _ptr(J)), "aoc_traj_cost")
+    return J[:B].cpu().numpy()
+
+
+def rollout_cost(problem, x0, uu, du=None, alpha=None, write=True):
+    """get_update + trial cost (reference optcon.py:176-200, :250-264).
+    x0 (B,6), uu (B,2,T), du (B,2,T) or None, alpha (B,) -> (xx (B,6,T), uu' (B,2,T), J (B,), status)"""
+    torch = _torch()
+    dev = problem.device
+    B = uu.shape[0]
+    ut = pack(uu, dev)
+    dt_ = None if du is None else pack(du, dev)
+    x0t = pack_vec(x0, dev)
+    nt = ntiles(B)
+    al = None
+    if du is not None:
+        al = torch.zeros(nt * TILE, dtype=torch.float64, device=dev)
+        al[:B] = _dev_f64(np.broadcast_to(np.asarray(alpha, dtype=np.float64), (B,)).copy(), dev)
+    xo = alloc_tiled(B, problem.T, 6, dev) if write else None
+    uo = alloc_tiled(B, problem.T, 2, dev) if write else None
+    J = torch.empty(nt * TILE, dtype=torch.float64, device=dev)
+    st = torch.zeros(nt * TILE, dtype=torch.int32, device=dev)
+    p = problem.c_problem(B)
+    check(lib().aoc_rollout_cost(C.byref(p), _ptr(x0t), _ptr(ut), _ptr(dt_), _ptr(al), _ptr(xo), _ptr(uo), _ptr(J),
+                                 _ptr(st)), "aoc_rollout_cost")
+    xx = unpack(xo, B).cpu().numpy() if write else None
+    un = unpack(uo, B).cpu().numpy() if write else None
+    return xx, un, J[:B].cpu().numpy(), st[:B].cpu().numpy()
+
+
+def backward_forward(problem, xx, uu, full_hessian, stepsize_0=1.0):
+    """One backward + forward pass (reference optcon.py:429-477 and the first Armijo trial).
+    Returns dict with K~ (B,2,7,T), g (B,2,T), du (B,2,T), descent (B,), lmbd0 (B,6),
+    xx_new, uu_new, J_new, status."""
+    torch = _torch()
+    dev = problem.device
+    B, T = xx.shape[0], problem.T
+    nt = ntiles(B)
+    xt, ut = pack(xx, dev), pack(uu, dev)
+    Kt = alloc_tiled(B, T, 14, dev, zero=True)
+    g = alloc_tiled(B, T, 2, dev, zero=True)
+    du = alloc_tiled(B, T, 2, dev)
+    xn, un = alloc_tiled(B, T, 6, dev), alloc_tiled(B, T, 2, dev)
+    lm0 = torch.empty((nt, 6, TILE), dtype=torch.float64, device=dev)
+    desc = torch.empty(nt * TILE, dtype=torch.float64, device=dev)
+    Jn = torch.empty(nt * TILE, dtype=torch.float64, device=dev)
+    st = torch.zeros(nt * TILE, dtype=torch.int32, device=dev)
+    x0t = xt[:, 0, :, :].contiguous()
+    p = problem.c_problem(B)
+    check(lib().aoc_backward(C.byref(p), int(bool(full_hessian)), _ptr(xt), _ptr(ut), _ptr(Kt), _ptr(g), _ptr(lm0),
+                             _ptr(st)), "aoc_backward")
+    check(lib().aoc_forward(C.byref(p), float(stepsize_0), _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(g), _ptr(du),
+                            _ptr(desc), _ptr(xn), _ptr(un), _ptr(Jn), _ptr(st)), "aoc_forward")
+    KK = unpack(Kt, B).cpu().numpy().reshape(B, 2, 7, T)
+    return dict(KK=KK, g=unpack(g, B).cpu().numpy(), du=unpack(du, B).cpu().numpy(),
+                descent=desc[:B].cpu().numpy(), lmbd0=lm0.permute(0, 2, 1).reshape(-1, 6)[:B].cpu().numpy(),
+                xx_new=unpack(xn, B).cpu().numpy(), uu_new=unpack(un, B).cpu().numpy(),
+                J_new=Jn[:B].cpu().numpy(), status=st[:B].cpu().numpy())

@@ -1,0 +1,343 @@
+// aoc_device.h — per-trajectory (per-lane) device math of the Newton/LQR path for gfx950.
+//
+// One lane owns one trajectory; everything here is straight-line fp64 register arithmetic on that
+// lane's state.  The 6x6 dynamics Jacobian is  A = I + N  with 11 structural non-zeros in N and the
+// input Jacobian B has 3, so the Riccati products are written out sparsely instead of as dense 6x6
+// (or, as the reference does, 7x7 augmented) matrix products.
+//
+// Reference behaviour reproduced here (file:line of the reference):
+//   Dynamics.step            aircraft_simplified.py:263-393  (x+ rounded to float32: :300)
+//   Cost.stagecost/termcost  aircraft_simplified.py:25-97
+//   ltv_LQR (augmented)      optcon.py:655-751  in the equivalent 6-dim affine form, see lqr_stage()
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace aoc {
+
+constexpr int TILE = 64;
+
+// Uniform (wave-invariant) constants: live in SGPRs / scalar loads from the kernarg segment.
+struct KConst {
+    // model (aircraft_simplified.py:108-118) and derived uniform values
+    double cd0, cda, cla, m, g, S, rho, J, dt;
+    double dtm;    // dt/m
+    double mg;     // m*g
+    double hrho;   // 0.5*rho
+    double krs;    // rho*S
+    double b41;    // dt/J
+    double Q[36], R[4], QT[36];
+    int T, ntiles, B, diag;  // diag: Q,R,QT all diagonal (every driver of the reference)
+};
+
+// ---------------------------------------------------------------------------------------------
+// tiled addressing: elem(tile, t, c, lane) = (((tile*T + t)*C + c)*64 + lane)
+// ---------------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ size_t tix(int tile, int T, int t, int c, int lane) {
+    return (((size_t)tile * T + t) * C + c) * TILE + lane;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Nonlinear step x+ = f(x,u) with the reference's float32 rounding of the result, and the stage
+// cost.  Written with contraction OFF and in the reference's association order so that a rollout
+// is bit-identical to NumPy's given identical sin/cos values.
+// ---------------------------------------------------------------------------------------------
+struct SC { double sg, cg, sa, ca; };
+
+__device__ __forceinline__ SC trig(double th, double ga) {
+    SC s;
+    double al = th - ga;
+    sincos(ga, &s.sg, &s.cg);
+    sincos(al, &s.sa, &s.ca);
+    return s;
+}
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ void step_state(const KConst& k, const double x[6], double u0, double u1,
+                                           const SC& s, double xp[6]) {
+    const double V = x[2], al = x[3] - x[5];
+    const double V2 = V * V;
+    const double D = k.hrho * V2 * k.S * (k.cd0 + k.cda * (al * al));   // aircraft_simplified.py:228
+    const double L = k.hrho * V2 * k.S * k.cla * al;                    // :253
+    xp[0] = (double)(float)(x[0] + k.dt * V * s.cg);                    // :303
+    xp[1] = (double)(float)(x[1] - k.dt * V * s.sg);                    // :304
+    xp[2] = (double)(float)(V + k.dtm * (-D - k.mg * s.sg + u0 * s.ca)); // :306
+    xp[3] = (double)(float)(x[3] + k.dt * x[4]);                        // :307
+    xp[4] = (double)(float)(x[4] + k.dt * (u1 / k.J));                  // :309
+    xp[5] = (double)(float)(x[5] + (k.dt / (k.m * V)) * (L - k.mg * s.cg + u0 * s.sa)); // :310
+}
+
+// l(x,u) = (0.5 dx)^T (Q dx) + (0.5 du)^T (R du)   (aircraft_simplified.py:61), ascending sums.
+// Also returns q = Q dx, r = R du (lx, lu at :63-64).
+template <bool DIAG>
+__device__ __forceinline__ double stage_cost(const KConst& k, const double x[6], double u0, double u1,
+                                             const double* __restrict__ ref, double q[6], double r[2]) {
+    double dx[6], du[2];
+#pragma unroll
+    for (int i = 0; i < 6; i++) dx[i] = x[i] - ref[i];
+    du[0] = u0 - ref[6];
+    du[1] = u1 - ref[7];
+    if (DIAG) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) q[i] = k.Q[i * 6 + i] * dx[i];
+        r[0] = k.R[0] * du[0];
+        r[1] = k.R[3] * du[1];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) a += k.Q[i * 6 + j] * dx[j];
+            q[i] = a;
+        }
+        r[0] = (0.0 + k.R[0] * du[0]) + k.R[1] * du[1];
+        r[1] = (0.0 + k.R[2] * du[0]) + k.R[3] * du[1];
+    }
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) a += (0.5 * dx[i]) * q[i];
+    b += (0.5 * du[0]) * r[0];
+    b += (0.5 * du[1]) * r[1];
+    return a + b;
+}
+
+// l_T(x) = ((0.5 dx)^T Q_T) dx, q_f = Q_T dx   (aircraft_simplified.py:92-94)
+template <bool DIAG>
+__device__ __forceinline__ double term_cost(const KConst& k, const double x[6],
+                                            const double* __restrict__ ref, double qf[6]) {
+    double dx[6], v[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) dx[i] = x[i] - ref[i];
+    if (DIAG) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) { v[i] = (0.5 * dx[i]) * k.QT[i * 6 + i]; qf[i] = k.QT[i * 6 + i] * dx[i]; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double a = 0.0, c = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) { a += (0.5 * dx[i]) * k.QT[i * 6 + j]; c += k.QT[j * 6 + i] * dx[i]; }
+            v[j] = a; qf[j] = c;
+        }
+    }
+    double ll = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) ll += v[j] * dx[j];
+    return ll;
+}
+#pragma clang fp contract(fast)
+
+// ---------------------------------------------------------------------------------------------
+// Linearisation  A = df/dx, B = df/du  at (x,u)   (aircraft_simplified.py:316-325)
+// Non-constant entries only; A00=A11=A33=A44=1, A34=dt, B41=dt/J.
+// ---------------------------------------------------------------------------------------------
+struct Lin {
+    double a02, a05, a12, a15, a22, a23, a25, a52, a53, a55;
+    double b20, b50;
+};
+
+__device__ __forceinline__ Lin linearise(const KConst& k, const double x[6], double u0, const SC& s) {
+    Lin l;
+    const double V = x[2], al = x[3] - x[5], V2 = V * V;
+    const double iV = 1.0 / V;
+    const double dtmV = k.dtm * iV;                     // dt/(m V)
+    l.a02 = k.dt * s.cg;
+    l.a05 = -k.dt * V * s.sg;
+    l.a12 = -k.dt * s.sg;
+    l.a15 = -k.dt * V * s.cg;
+    const double cdt = k.cd0 + k.cda * al * al;
+    l.a22 = 1.0 - k.dtm * (k.krs * V * cdt);
+    const double dA = k.cda * k.krs * al * V2 + u0 * s.sa;     // (Cda S rho 2 al V^2)/2 + u0 sin(al)
+    l.a23 = -k.dtm * dA;
+    l.a25 = k.dtm * (dA - k.mg * s.cg);
+    const double hl = 0.5 * k.cla * k.krs * V2;                // Cla S rho V^2 / 2
+    const double lA = hl * al + u0 * s.sa - k.mg * s.cg;
+    l.a52 = k.dtm * (k.cla * k.krs * al) - dtmV * iV * lA;
+    const double lB = hl + u0 * s.ca;
+    l.a53 = dtmV * lB;
+    l.a55 = 1.0 - dtmV * (lB - k.mg * s.sg);
+    l.b20 = k.dtm * s.ca;
+    l.b50 = dtmV * s.sa;
+    return l;
+}
+
+// Second-order terms contracted with the costate (aircraft_simplified.py:339-388): the symmetric
+// 6x6  sum_k lam_k d2f_k/dx2  has six distinct non-zeros, the 2x6  sum_k lam_k d2f_k/dudx  three
+// (row 0 only); d2f/du2 == 0.
+struct Hess {
+    double h22, h23, h25, h33, h35, h55;  // fxx
+    double s02, s03, s05;                 // fux row 0
+};
+
+__device__ __forceinline__ Hess hessian(const KConst& k, const double x[6], double u0, const SC& s,
+                                        const double lam[6]) {
+    Hess h;
+    const double V = x[2], al = x[3] - x[5], V2 = V * V;
+    const double iV = 1.0 / V, iV2 = iV * iV;
+    const double dtmV = k.dtm * iV, dtmV2 = k.dtm * iV2;
+    const double l0 = lam[0], l1 = lam[1], l2 = lam[2], l5 = lam[5];
+    // k = 0, 1  (:339-352)
+    const double f0_25 = -k.dt * s.sg, f0_55 = -k.dt * V * s.cg;
+    const double f1_25 = -k.dt * s.cg, f1_55 = k.dt * V * s.sg;
+    // k = 2  (:354-359)
+    const double f2_22 = -k.dtm * (k.krs * (k.cd0 + k.cda * al * al));
+    const double f2_23 = -k.dtm * (k.cda * k.krs * V * (2.0 * al));
+    const double e2 = k.cda * k.krs * V2 + u0 * s.ca;
+    const double f2_33 = -k.dtm * e2;
+    const double f2_55 = -k.dtm * (e2 - k.mg * s.sg);
+    // k = 5  (:361-366)
+    const double hl = 0.5 * k.cla * k.krs * V2;
+    const double lA = hl * al + u0 * s.sa - k.mg * s.cg;
+    const double cl = k.cla * k.krs * k.dtm;                    // Cla S dt rho / m
+    const double f5_22 = 2.0 * dtmV2 * iV * lA - cl * al * iV;
+    const double lB = hl + u0 * s.ca;
+    const double f5_23 = cl - dtmV2 * lB;
+    const double f5_25 = dtmV2 * (lB - k.mg * s.sg) - cl;
+    const double f5_33 = -dtmV * (u0 * s.sa);
+    const double f5_55 = -dtmV * (u0 * s.sa - k.mg * s.cg);
+    h.h22 = l2 * f2_22 + l5 * f5_22;
+    h.h23 = l2 * f2_23 + l5 * f5_23;
+    h.h25 = l0 * f0_25 + l1 * f1_25 - l2 * f2_23 + l5 * f5_25;
+    h.h33 = l2 * f2_33 + l5 * f5_33;
+    h.h35 = -l2 * f2_33 - l5 * f5_33;
+    h.h55 = l0 * f0_55 + l1 * f1_55 + l2 * f2_55 + l5 * f5_55;
+    // fux (:375-379)
+    const double g2_03 = -k.dtm * s.sa;
+    const double g5_02 = -dtmV2 * s.sa, g5_03 = dtmV * s.ca;
+    h.s02 = l5 * g5_02;
+    h.s03 = l2 * g2_03 + l5 * g5_03;
+    h.s05 = -l2 * g2_03 - l5 * g5_03;
+    return h;
+}
+
+// y = A^T v  (sparse)
+__device__ __forceinline__ void At_vec(const KConst& k, const Lin& l, const double v[6], double y[6]) {
+    y[0] = v[0];
+    y[1] = v[1];
+    y[2] = l.a02 * v[0] + l.a12 * v[1] + l.a22 * v[2] + l.a52 * v[5];
+    y[3] = l.a23 * v[2] + v[3] + l.a53 * v[5];
+    y[4] = k.dt * v[3] + v[4];
+    y[5] = l.a05 * v[0] + l.a15 * v[1] + l.a25 * v[2] + l.a55 * v[5];
+}
+
+// y = A v  (sparse)
+__device__ __forceinline__ void A_vec(const KConst& k, const Lin& l, const double v[6], double y[6]) {
+    y[0] = v[0] + l.a02 * v[2] + l.a05 * v[5];
+    y[1] = v[1] + l.a12 * v[2] + l.a15 * v[5];
+    y[2] = l.a22 * v[2] + l.a23 * v[3] + l.a25 * v[5];
+    y[3] = v[3] + k.dt * v[4];
+    y[4] = v[4];
+    y[5] = l.a52 * v[2] + l.a53 * v[3] + l.a55 * v[5];
+}
+
+// symmetric 6x6 stored as upper triangle, index of (i,j), i<=j
+__host__ __device__ constexpr int sidx(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+#define SYM(P, i, j) ((i) <= (j) ? P[sidx((i), (j))] : P[sidx((j), (i))])
+
+// ---------------------------------------------------------------------------------------------
+// One stage of the affine LTV-LQR backward recursion in 6-dim form.
+//
+// The reference augments the state with a constant 1 (optcon.py:655-690):
+//   P~ = [[c, p^T],[p, P]],  A~ = blkdiag(1,A),  B~ = [0;B],  Q~ = [[0,q^T/2],[q/2,Q]],  S~ = [r/2, S]
+// so that its 7x7 recursion (optcon.py:719-728) and gain formula (:732-751) read, block-wise,
+//   G  = B^T P A + S                 (2x6)        h = B^T p + r/2        (2)
+//   M  = R + B^T P B                 (2x2)
+//   P_t = Q + A^T P A - G^T M^-1 G                p_t = q/2 + A^T p - G^T M^-1 h
+//   K~_t = -Mreg^-1 [h, G]   with Mreg = M, or M + 0.5 I when M is not positive definite (:745-749;
+//                            the Riccati update itself always uses the unregularised M — Q3)
+// P is carried as a symmetric matrix (the reference's P is symmetric to rounding, |P-P^T|<=7e-11).
+// Inputs: P,p at t+1; Q (sym upper, incl. Hessian terms), S row 0 entries, q/2, r/2.  Outputs: P,p
+// at t (in place), Kt[14] = {sigma0, K0[0..5], sigma1, K1[0..5]} and flags.
+// ---------------------------------------------------------------------------------------------
+struct StageFlags { bool singular, regularised; };
+
+__device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, double P[21], double p[6],
+                                                const double Qs[21], double s02, double s03, double s05,
+                                                const double hq[6], const double hr[2], double Kt[14]) {
+    // W = P A  (6x6, full)
+    double W[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double pi0 = SYM(P, i, 0), pi1 = SYM(P, i, 1), pi2 = SYM(P, i, 2), pi3 = SYM(P, i, 3),
+                     pi4 = SYM(P, i, 4), pi5 = SYM(P, i, 5);
+        W[i][0] = pi0;
+        W[i][1] = pi1;
+        W[i][2] = pi0 * l.a02 + pi1 * l.a12 + pi2 * l.a22 + pi5 * l.a52;
+        W[i][3] = pi2 * l.a23 + pi3 + pi5 * l.a53;
+        W[i][4] = pi3 * k.dt + pi4;
+        W[i][5] = pi0 * l.a05 + pi1 * l.a15 + pi2 * l.a25 + pi5 * l.a55;
+    }
+    // G = B^T W + S (2x6), h = B^T p + r/2
+    double G0[6], G1[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        G0[j] = l.b20 * W[2][j] + l.b50 * W[5][j];
+        G1[j] = k.b41 * W[4][j];
+    }
+    G0[2] += s02; G0[3] += s03; G0[5] += s05;
+    const double h0 = l.b20 * p[2] + l.b50 * p[5] + hr[0];
+    const double h1 = k.b41 * p[4] + hr[1];
+    // M = R + B^T P B
+    const double P22 = P[sidx(2, 2)], P24 = P[sidx(2, 4)], P25 = P[sidx(2, 5)], P44 = P[sidx(4, 4)],
+                 P45 = P[sidx(4, 5)], P55 = P[sidx(5, 5)];
+    const double bp2 = l.b20 * P22 + l.b50 * P25;   // (B^T P)[0,2]
+    const double bp5 = l.b20 * P25 + l.b50 * P55;   // (B^T P)[0,5]
+    const double bp4 = l.b20 * P24 + l.b50 * P45;   // (B^T P)[0,4]
+    const double M00 = k.R[0] + (bp2 * l.b20 + bp5 * l.b50);
+    const double M01 = k.R[1] + bp4 * k.b41;
+    const double M11 = k.R[3] + (k.b41 * P44) * k.b41;
+    StageFlags fl;
+    const double det = M00 * M11 - M01 * M01;
+    fl.singular = (det == 0.0);
+    const double idet = 1.0 / det;
+    const double i00 = M11 * idet, i01 = -M01 * idet, i11 = M00 * idet;
+    // MiG = M^-1 [h, G]
+    const double mh0 = i00 * h0 + i01 * h1, mh1 = i01 * h0 + i11 * h1;
+    double MG0[6], MG1[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        MG0[j] = i00 * G0[j] + i01 * G1[j];
+        MG1[j] = i01 * G0[j] + i11 * G1[j];
+    }
+    // gains; M positive definite <=> tr > 0 and det > 0 (equivalent to all(eigvals(M) > 0), :745)
+    const bool pd = (M00 + M11 > 0.0) && (det > 0.0);
+    fl.regularised = !pd;
+    if (pd) {
+        Kt[0] = -mh0; Kt[7] = -mh1;
+#pragma unroll
+        for (int j = 0; j < 6; j++) { Kt[1 + j] = -MG0[j]; Kt[8 + j] = -MG1[j]; }
+    } else {
+        const double r00 = M00 + 0.5, r11 = M11 + 0.5;
+        const double rdet = r00 * r11 - M01 * M01;
+        if (rdet == 0.0) fl.singular = true;
+        const double ird = 1.0 / rdet;
+        const double j00 = r11 * ird, j01 = -M01 * ird, j11 = r00 * ird;
+        Kt[0] = -(j00 * h0 + j01 * h1); Kt[7] = -(j01 * h0 + j11 * h1);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            Kt[1 + j] = -(j00 * G0[j] + j01 * G1[j]);
+            Kt[8 + j] = -(j01 * G0[j] + j11 * G1[j]);
+        }
+    }
+    // p_t = q/2 + A^T p - G^T (M^-1 h)
+    double ap[6];
+    At_vec(k, l, p, ap);
+#pragma unroll
+    for (int i = 0; i < 6; i++) p[i] = hq[i] + ap[i] - (G0[i] * mh0 + G1[i] * mh1);
+    // P_t = Q + A^T W - G^T (M^-1 G), upper triangle
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const double z0 = W[0][j], z1 = W[1][j];
+        const double z2 = l.a02 * W[0][j] + l.a12 * W[1][j] + l.a22 * W[2][j] + l.a52 * W[5][j];
+        const double z3 = l.a23 * W[2][j] + W[3][j] + l.a53 * W[5][j];
+        const double z4 = k.dt * W[3][j] + W[4][j];
+        const double z5 = l.a05 * W[0][j] + l.a15 * W[1][j] + l.a25 * W[2][j] + l.a55 * W[5][j];
+        const double z[6] = {z0, z1, z2, z3, z4, z5};
+#pragma unroll
+        for (int i = 0; i <= j; i++)
+            P[sidx(i, j)] = Qs[sidx(i, j)] + z[i] - (G0[i] * MG0[j] + G1[i] * MG1[j]);
+    }
+    return fl;
+}
+
+}  // namespace aoc

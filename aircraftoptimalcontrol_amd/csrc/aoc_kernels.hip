@@ -1,0 +1,632 @@
+// aoc_kernels.hip — HIP kernels (gfx950) and the C-ABI of libaoc_hip.so (include/aoc.h).
+//
+// Execution model: one wavefront (64 lanes) per tile of 64 trajectories, one trajectory per lane,
+// one workgroup = one wavefront.  Every pass walks the horizon sequentially inside the lane; the
+// batch axis is the lane axis, so each (t, component) access of a wavefront is one coalesced 512-B
+// segment and a wavefront streams through its own contiguous slab of every array.
+// No MFMA (the blocks are 6x6/6x2), no LDS traffic in these first kernels: the per-lane state
+// (P: 21, p: 6, lambda: 6 doubles, ...) lives in VGPRs.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/aoc.h"
+#include "aoc_device.h"
+
+using namespace aoc;
+
+// ---------------------------------------------------------------------------------------------
+// layout conversion
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pack(int B, int T, int C, const double* __restrict__ src, double* __restrict__ dst) {
+    // one block per (tile, chunk of t); threads: lane fastest on the write side
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    int b = tile * TILE + lane;
+    if (b >= B) b = B - 1;
+    for (int t = blockIdx.y; t < T; t += gridDim.y)
+        for (int c = 0; c < C; c++)
+            dst[(((size_t)tile * T + t) * C + c) * TILE + lane] = src[((size_t)b * C + c) * T + t];
+}
+
+__global__ void k_unpack(int B, int T, int C, const double* __restrict__ src, double* __restrict__ dst) {
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const int b = tile * TILE + lane;
+    if (b >= B) return;
+    for (int t = blockIdx.y; t < T; t += gridDim.y)
+        for (int c = 0; c < C; c++)
+            dst[((size_t)b * C + c) * T + t] = src[(((size_t)tile * T + t) * C + c) * TILE + lane];
+}
+
+// ---------------------------------------------------------------------------------------------
+// unit-level kernels (AoS points, one per thread)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_step_batch(KConst k, int n, const double* __restrict__ x, const double* __restrict__ u,
+                             const double* __restrict__ lmbd, double* __restrict__ xp, double* __restrict__ fx,
+                             double* __restrict__ fu, double* __restrict__ fxx, double* __restrict__ fuu,
+                             double* __restrict__ fux) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double xs[6], xn[6];
+    for (int c = 0; c < 6; c++) xs[c] = x[(size_t)i * 6 + c];
+    const double u0 = u[(size_t)i * 2], u1 = u[(size_t)i * 2 + 1];
+    const SC s = trig(xs[3], xs[5]);
+    step_state(k, xs, u0, u1, s, xn);
+    for (int c = 0; c < 6; c++) xp[(size_t)i * 6 + c] = xn[c];
+    const Lin l = linearise(k, xs, u0, s);
+    if (fx) {  // fx = A^T (aircraft_simplified.py:322)
+        double A[36];
+        for (int e = 0; e < 36; e++) A[e] = 0.0;
+        A[0] = 1; A[7] = 1; A[21] = 1; A[28] = 1; A[3 * 6 + 4] = k.dt;
+        A[0 * 6 + 2] = l.a02; A[0 * 6 + 5] = l.a05; A[1 * 6 + 2] = l.a12; A[1 * 6 + 5] = l.a15;
+        A[2 * 6 + 2] = l.a22; A[2 * 6 + 3] = l.a23; A[2 * 6 + 5] = l.a25;
+        A[5 * 6 + 2] = l.a52; A[5 * 6 + 3] = l.a53; A[5 * 6 + 5] = l.a55;
+        for (int r = 0; r < 6; r++)
+            for (int c = 0; c < 6; c++) fx[(size_t)i * 36 + r * 6 + c] = A[c * 6 + r];
+    }
+    if (fu) {
+        for (int e = 0; e < 12; e++) fu[(size_t)i * 12 + e] = 0.0;
+        fu[(size_t)i * 12 + 2] = l.b20; fu[(size_t)i * 12 + 5] = l.b50; fu[(size_t)i * 12 + 6 + 4] = k.b41;
+    }
+    if (lmbd) {
+        double lam[6];
+        for (int c = 0; c < 6; c++) lam[c] = lmbd[(size_t)i * 6 + c];
+        const Hess h = hessian(k, xs, u0, s, lam);
+        if (fxx) {
+            double* F = fxx + (size_t)i * 36;
+            for (int e = 0; e < 36; e++) F[e] = 0.0;
+            F[2 * 6 + 2] = h.h22; F[2 * 6 + 3] = h.h23; F[3 * 6 + 2] = h.h23; F[2 * 6 + 5] = h.h25; F[5 * 6 + 2] = h.h25;
+            F[3 * 6 + 3] = h.h33; F[3 * 6 + 5] = h.h35; F[5 * 6 + 3] = h.h35; F[5 * 6 + 5] = h.h55;
+        }
+        if (fux) {
+            double* G = fux + (size_t)i * 12;
+            for (int e = 0; e < 12; e++) G[e] = 0.0;
+            G[2] = h.s02; G[3] = h.s03; G[5] = h.s05;
+        }
+        if (fuu) for (int e = 0; e < 4; e++) fuu[(size_t)i * 4 + e] = 0.0;
+    }
+}
+
+template <bool DIAG>
+__global__ void k_cost_batch(KConst k, int n, const double* __restrict__ x, const double* __restrict__ u,
+                             const double* __restrict__ xr, const double* __restrict__ ur, double* __restrict__ ll,
+                             double* __restrict__ lx, double* __restrict__ lu, double* __restrict__ llT,
+                             double* __restrict__ lTx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double xs[6], ref[8], q[6], r[2];
+    for (int c = 0; c < 6; c++) { xs[c] = x[(size_t)i * 6 + c]; ref[c] = xr[(size_t)i * 6 + c]; }
+    const double u0 = u[(size_t)i * 2], u1 = u[(size_t)i * 2 + 1];
+    ref[6] = ur[(size_t)i * 2]; ref[7] = ur[(size_t)i * 2 + 1];
+    const double l = stage_cost<DIAG>(k, xs, u0, u1, ref, q, r);
+    if (ll) ll[i] = l;
+    if (lx) for (int c = 0; c < 6; c++) lx[(size_t)i * 6 + c] = q[c];
+    if (lu) { lu[(size_t)i * 2] = r[0]; lu[(size_t)i * 2 + 1] = r[1]; }
+    const double lT = term_cost<DIAG>(k, xs, ref, q);
+    if (llT) llT[i] = lT;
+    if (lTx) for (int c = 0; c < 6; c++) lTx[(size_t)i * 6 + c] = q[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// pass-level kernels: one wavefront per tile
+// ---------------------------------------------------------------------------------------------
+
+// cost of a stored trajectory, t ascending then terminal (optcon.py:417-424)
+template <bool DIAG>
+__global__ __launch_bounds__(TILE) void k_traj_cost(KConst k, const double* __restrict__ ref,
+                                                    const double* __restrict__ x, const double* __restrict__ u,
+                                                    double* __restrict__ J) {
+    const int tile = blockIdx.x, lane = threadIdx.x, T = k.T;
+    double JJ = 0.0, xs[6], q[6], r[2];
+    for (int t = 0; t < T - 1; t++) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) xs[c] = x[tix<6>(tile, T, t, c, lane)];
+        const double u0 = u[tix<2>(tile, T, t, 0, lane)], u1 = u[tix<2>(tile, T, t, 1, lane)];
+        JJ += stage_cost<DIAG>(k, xs, u0, u1, ref + (size_t)t * 8, q, r);
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) xs[c] = x[tix<6>(tile, T, T - 1, c, lane)];
+    JJ += term_cost<DIAG>(k, xs, ref + (size_t)(T - 1) * 8, q);
+    J[tile * TILE + lane] = JJ;
+}
+
+// One nonlinear rollout with cost for per-lane step `a` (get_update + trial cost).
+// WRITE: store x',u'.  wmask: lane writes (and reports J) only if true.
+template <bool DIAG, bool WRITE>
+__device__ __forceinline__ double rollout(const KConst& k, const double* __restrict__ ref, int tile, int lane,
+                                          const double x0[6], const double* __restrict__ u,
+                                          const double* __restrict__ du, double a, bool wmask,
+                                          double* __restrict__ x_out, double* __restrict__ u_out, int& flags) {
+    const int T = k.T;
+    double xs[6], xn[6], q[6], r[2];
+    double JJ = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) xs[c] = x0[c];
+    if (WRITE && wmask) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) x_out[tix<6>(tile, T, 0, c, lane)] = xs[c];
+    }
+    double un0 = u[tix<2>(tile, T, 0, 0, lane)], un1 = u[tix<2>(tile, T, 0, 1, lane)];
+    double dn0 = du ? du[tix<2>(tile, T, 0, 0, lane)] : 0.0, dn1 = du ? du[tix<2>(tile, T, 0, 1, lane)] : 0.0;
+    for (int t = 0; t < T - 1; t++) {
+        const double uc0 = un0, uc1 = un1, dc0 = dn0, dc1 = dn1;
+        if (t + 1 < T - 1) {  // prefetch next stage
+            un0 = u[tix<2>(tile, T, t + 1, 0, lane)]; un1 = u[tix<2>(tile, T, t + 1, 1, lane)];
+            if (du) { dn0 = du[tix<2>(tile, T, t + 1, 0, lane)]; dn1 = du[tix<2>(tile, T, t + 1, 1, lane)]; }
+        }
+        double u0, u1;
+        {
+#pragma clang fp contract(off)
+            u0 = uc0 + a * dc0;  // optcon.py:197 / :253
+            u1 = uc1 + a * dc1;
+        }
+        JJ += stage_cost<DIAG>(k, xs, u0, u1, ref + (size_t)t * 8, q, r);
+        if (!(xs[2] > 0.0)) flags |= AOC_ST_VNONPOS;
+        const SC s = trig(xs[3], xs[5]);
+        step_state(k, xs, u0, u1, s, xn);
+        if (WRITE && wmask) {
+            u_out[tix<2>(tile, T, t, 0, lane)] = u0;
+            u_out[tix<2>(tile, T, t, 1, lane)] = u1;
+#pragma unroll
+            for (int c = 0; c < 6; c++) x_out[tix<6>(tile, T, t + 1, c, lane)] = xn[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) xs[c] = xn[c];
+    }
+    JJ += term_cost<DIAG>(k, xs, ref + (size_t)(T - 1) * 8, q);
+    if (WRITE && wmask) {
+        u_out[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;  // optcon.py:193: uu_temp[:, T-1] stays 0
+        u_out[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
+    }
+    return JJ;
+}
+
+template <bool DIAG, bool WRITE>
+__global__ __launch_bounds__(TILE) void k_rollout_cost(KConst k, const double* __restrict__ ref,
+                                                       const double* __restrict__ x0, const double* __restrict__ u,
+                                                       const double* __restrict__ du, const double* __restrict__ alpha,
+                                                       double* __restrict__ x_out, double* __restrict__ u_out,
+                                                       double* __restrict__ J_out, int* __restrict__ status) {
+    const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane;
+    double xs[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
+    const double a = (du && alpha) ? alpha[b] : 0.0;
+    int flags = 0;
+    const double JJ = rollout<DIAG, WRITE>(k, ref, tile, lane, xs, u, du, a, true, x_out, u_out, flags);
+    if (JJ != JJ || JJ - JJ != 0.0) flags |= AOC_ST_NAN;
+    J_out[b] = JJ;
+    if (status && flags) status[b] |= flags;
+}
+
+// Backward pass (see aoc_backward in include/aoc.h).
+template <bool DIAG, bool FULL>
+__global__ __launch_bounds__(TILE) void k_backward(KConst k, const double* __restrict__ ref,
+                                                   const double* __restrict__ x, const double* __restrict__ u,
+                                                   double* __restrict__ Kt, double* __restrict__ g,
+                                                   double* __restrict__ lmbd0, int* __restrict__ status) {
+    const int tile = blockIdx.x, lane = threadIdx.x, T = k.T;
+    double P[21], p[6], lam[6], Qb[21], xs[6], q[6], r[2];
+    int flags = 0;
+    // terminal condition (optcon.py:429-432, :688-690, :716): P = Q_T, p = q_f/2, lambda = q_f
+#pragma unroll
+    for (int c = 0; c < 6; c++) xs[c] = x[tix<6>(tile, T, T - 1, c, lane)];
+    term_cost<DIAG>(k, xs, ref + (size_t)(T - 1) * 8, q);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        lam[i] = q[i];
+        p[i] = 0.5 * q[i];
+#pragma unroll
+        for (int j = i; j < 6; j++) {
+            P[sidx(i, j)] = k.QT[i * 6 + j];
+            Qb[sidx(i, j)] = k.Q[i * 6 + j];
+        }
+    }
+    double xn[6], un0, un1;
+#pragma unroll
+    for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, T - 2, c, lane)];
+    un0 = u[tix<2>(tile, T, T - 2, 0, lane)];
+    un1 = u[tix<2>(tile, T, T - 2, 1, lane)];
+    for (int t = T - 2; t >= 0; t--) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) xs[c] = xn[c];
+        const double u0 = un0, u1 = un1;
+        if (t > 0) {  // prefetch stage t-1 while stage t computes
+#pragma unroll
+            for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, t - 1, c, lane)];
+            un0 = u[tix<2>(tile, T, t - 1, 0, lane)];
+            un1 = u[tix<2>(tile, T, t - 1, 1, lane)];
+        }
+        stage_cost<DIAG>(k, xs, u0, u1, ref + (size_t)t * 8, q, r);  // q = l_x, r = l_u (optcon.py:436)
+        const SC s = trig(xs[3], xs[5]);
+        const Lin l = linearise(k, xs, u0, s);
+        // g = B^T lambda_{t+1} + r   (optcon.py:475)
+        const double g0 = l.b20 * lam[2] + l.b50 * lam[5] + r[0];
+        const double g1 = k.b41 * lam[4] + r[1];
+        double Qs[21];
+#pragma unroll
+        for (int e = 0; e < 21; e++) Qs[e] = Qb[e];
+        double s02 = 0.0, s03 = 0.0, s05 = 0.0;
+        if (FULL) {  // kk > 8: Q += fxx.lambda, S = fux.lambda (optcon.py:443-446)
+            const Hess h = hessian(k, xs, u0, s, lam);
+            Qs[sidx(2, 2)] += h.h22; Qs[sidx(2, 3)] += h.h23; Qs[sidx(2, 5)] += h.h25;
+            Qs[sidx(3, 3)] += h.h33; Qs[sidx(3, 5)] += h.h35; Qs[sidx(5, 5)] += h.h55;
+            s02 = h.s02; s03 = h.s03; s05 = h.s05;
+        }
+        double hq[6], hr[2], Ks[14];
+#pragma unroll
+        for (int i = 0; i < 6; i++) hq[i] = 0.5 * q[i];   // optcon.py:673-674 (Q2)
+        hr[0] = 0.5 * r[0]; hr[1] = 0.5 * r[1];           // optcon.py:679
+        const StageFlags fl = lqr_stage(k, l, P, p, Qs, s02, s03, s05, hq, hr, Ks);
+        if (fl.singular) flags |= AOC_ST_SINGULAR;
+        if (fl.regularised) flags |= AOC_ST_REGULARISED;
+        // costate: lambda_t = A^T lambda_{t+1} + l_x   (optcon.py:461)
+        double al[6];
+        At_vec(k, l, lam, al);
+#pragma unroll
+        for (int i = 0; i < 6; i++) lam[i] = al[i] + q[i];
+#pragma unroll
+        for (int c = 0; c < 14; c++) Kt[tix<14>(tile, T, t, c, lane)] = Ks[c];
+        g[tix<2>(tile, T, t, 0, lane)] = g0;
+        g[tix<2>(tile, T, t, 1, lane)] = g1;
+    }
+    if (lmbd0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) lmbd0[((size_t)tile * 6 + c) * TILE + lane] = lam[c];
+    }
+    if (status && flags) status[tile * TILE + lane] |= flags;
+}
+
+// Forward pass (see aoc_forward in include/aoc.h).
+template <bool DIAG>
+__global__ __launch_bounds__(TILE) void k_forward(KConst k, double alpha0, const double* __restrict__ ref,
+                                                  const double* __restrict__ x, const double* __restrict__ u,
+                                                  const double* __restrict__ x0, const double* __restrict__ Kt,
+                                                  const double* __restrict__ g, double* __restrict__ du_out,
+                                                  double* __restrict__ descent, double* __restrict__ x_new,
+                                                  double* __restrict__ u_new, double* __restrict__ J_new,
+                                                  int* __restrict__ status) {
+    const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane, T = k.T;
+    double dx[6], xp[6], xpn[6], q[6], r[2];
+    int flags = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        dx[c] = 0.0;  // ltv_LQR is called with x0 = 0 (optcon.py:470)
+        xp[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
+        x_new[tix<6>(tile, T, 0, c, lane)] = xp[c];
+    }
+    double desc = 0.0, JJ = 0.0;
+    // software prefetch of stage t+1 operands
+    double Kn[14], gn0, gn1, xn[6], un0, un1;
+#pragma unroll
+    for (int c = 0; c < 14; c++) Kn[c] = Kt[tix<14>(tile, T, 0, c, lane)];
+    gn0 = g[tix<2>(tile, T, 0, 0, lane)]; gn1 = g[tix<2>(tile, T, 0, 1, lane)];
+#pragma unroll
+    for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, 0, c, lane)];
+    un0 = u[tix<2>(tile, T, 0, 0, lane)]; un1 = u[tix<2>(tile, T, 0, 1, lane)];
+    for (int t = 0; t < T - 1; t++) {
+        double Kc[14], xs[6];
+#pragma unroll
+        for (int c = 0; c < 14; c++) Kc[c] = Kn[c];
+#pragma unroll
+        for (int c = 0; c < 6; c++) xs[c] = xn[c];
+        const double g0 = gn0, g1 = gn1, uc0 = un0, uc1 = un1;
+        if (t + 1 < T - 1) {
+#pragma unroll
+            for (int c = 0; c < 14; c++) Kn[c] = Kt[tix<14>(tile, T, t + 1, c, lane)];
+            gn0 = g[tix<2>(tile, T, t + 1, 0, lane)]; gn1 = g[tix<2>(tile, T, t + 1, 1, lane)];
+#pragma unroll
+            for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, t + 1, c, lane)];
+            un0 = u[tix<2>(tile, T, t + 1, 0, lane)]; un1 = u[tix<2>(tile, T, t + 1, 1, lane)];
+        }
+        // du_t = K~_t [1; dx_t]   (optcon.py:759)
+        double d0 = Kc[0], d1 = Kc[7];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { d0 += Kc[1 + j] * dx[j]; d1 += Kc[8 + j] * dx[j]; }
+        desc += g0 * d0 + g1 * d1;  // optcon.py:475-477
+        // dx_{t+1} = A dx_t + B du_t   (optcon.py:760), A,B re-linearised at the nominal (x_t,u_t)
+        {
+            const SC s = trig(xs[3], xs[5]);
+            const Lin l = linearise(k, xs, uc0, s);
+            double ax[6];
+            A_vec(k, l, dx, ax);
+            dx[0] = ax[0]; dx[1] = ax[1];
+            dx[2] = ax[2] + l.b20 * d0;
+            dx[3] = ax[3];
+            dx[4] = ax[4] + k.b41 * d1;
+            dx[5] = ax[5] + l.b50 * d0;
+        }
+        du_out[tix<2>(tile, T, t, 0, lane)] = d0;
+        du_out[tix<2>(tile, T, t, 1, lane)] = d1;
+        // first Armijo trial, step alpha0 (optcon.py:250-264)
+        double u0, u1;
+        {
+#pragma clang fp contract(off)
+            u0 = uc0 + alpha0 * d0;
+            u1 = uc1 + alpha0 * d1;
+        }
+        JJ += stage_cost<DIAG>(k, xp, u0, u1, ref + (size_t)t * 8, q, r);
+        if (!(xp[2] > 0.0)) flags |= AOC_ST_VNONPOS;
+        const SC s2 = trig(xp[3], xp[5]);
+        step_state(k, xp, u0, u1, s2, xpn);
+        u_new[tix<2>(tile, T, t, 0, lane)] = u0;
+        u_new[tix<2>(tile, T, t, 1, lane)] = u1;
+#pragma unroll
+        for (int c = 0; c < 6; c++) { x_new[tix<6>(tile, T, t + 1, c, lane)] = xpn[c]; xp[c] = xpn[c]; }
+    }
+    JJ += term_cost<DIAG>(k, xp, ref + (size_t)(T - 1) * 8, q);
+    du_out[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
+    du_out[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
+    u_new[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
+    u_new[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
+    if (JJ != JJ || JJ - JJ != 0.0 || desc != desc || desc - desc != 0.0) flags |= AOC_ST_NAN;
+    descent[b] = desc;
+    J_new[b] = JJ;
+    if (status && flags) status[b] |= flags;
+}
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ bool armijo_reject(double Jt, double JP, double cc, double a, double descent) {
+    return Jt > JP + cc * a * descent;  // optcon.py:268
+}
+#pragma clang fp contract(fast)
+
+// Armijo back-tracking after the first trial + final update (see aoc_linesearch in include/aoc.h).
+template <bool DIAG>
+__global__ __launch_bounds__(TILE) void k_linesearch(KConst k, aoc_params prm, const double* __restrict__ ref,
+                                                     const double* __restrict__ u, const double* __restrict__ x0,
+                                                     const double* __restrict__ du, const double* __restrict__ J_cur,
+                                                     const double* __restrict__ descent, double* __restrict__ x_new,
+                                                     double* __restrict__ u_new, double* __restrict__ J_new,
+                                                     double* __restrict__ stepsize, int* __restrict__ ntrials,
+                                                     int* __restrict__ status) {
+    const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane;
+    const double JP = J_cur[b], d = descent[b];
+    double a = prm.stepsize_0;
+    int ntr = 1, flags = 0;
+    bool done = !armijo_reject(J_new[b], JP, prm.cc, a, d);
+    const bool first_ok = done;
+    if (__all(done)) {  // whole wavefront accepted the first trial: nothing to do
+        stepsize[b] = a;
+        ntrials[b] = 1;
+        return;
+    }
+    if (!done) a = prm.beta * a;  // optcon.py:270
+    double xs[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
+    for (int ii = 1; ii < prm.armijo_maxiters; ii++) {
+        if (__all(done)) break;
+        int f2 = 0;
+        const double Jt = rollout<DIAG, false>(k, ref, tile, lane, xs, u, du, a, false, nullptr, nullptr, f2);
+        if (!done) {
+            ntr++;
+            if (armijo_reject(Jt, JP, prm.cc, a, d)) a = prm.beta * a;
+            else done = true;
+        }
+    }
+    if (!done) flags |= AOC_ST_ARMIJO_EXH;  // `a` is now the never-evaluated stepsize_0*beta^maxiters (Q5)
+    // final update (optcon.py:488-491) for the lanes whose first trial was rejected
+    const double Jf = rollout<DIAG, true>(k, ref, tile, lane, xs, u, du, a, !first_ok, x_new, u_new, flags);
+    if (!first_ok) {
+        if (Jf != Jf || Jf - Jf != 0.0) flags |= AOC_ST_NAN;
+        J_new[b] = Jf;
+        stepsize[b] = a;
+        ntrials[b] = ntr;
+        if (status && flags) status[b] |= flags;
+    } else {
+        stepsize[b] = prm.stepsize_0;
+        ntrials[b] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side of the C-ABI
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_hip_err[256] = "";
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, hipGetErrorString(e));
+        return AOC_ELAUNCH;
+    }
+    return AOC_OK;
+}
+
+static bool is_diag(const double* M, int n) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+            if (i != j && M[i * n + j] != 0.0) return false;
+    return true;
+}
+
+static KConst make_const(const aoc_model& md, const double* Q, const double* R, const double* QT, int B, int T) {
+    KConst k;
+    memset(&k, 0, sizeof k);
+    k.cd0 = md.cd0; k.cda = md.cda; k.cla = md.cla; k.m = md.m; k.g = md.g; k.S = md.S; k.rho = md.rho;
+    k.J = md.J; k.dt = md.dt;
+    k.dtm = md.dt / md.m;
+    k.mg = md.m * md.g;
+    k.hrho = 0.5 * md.rho;
+    k.krs = md.rho * md.S;
+    k.b41 = md.dt / md.J;
+    if (Q) memcpy(k.Q, Q, sizeof k.Q);
+    if (R) memcpy(k.R, R, sizeof k.R);
+    if (QT) memcpy(k.QT, QT, sizeof k.QT);
+    k.B = B; k.T = T; k.ntiles = (B + TILE - 1) / TILE;
+    k.diag = (Q && R && QT) ? (is_diag(Q, 6) && is_diag(R, 2) && is_diag(QT, 6)) : 1;
+    return k;
+}
+
+static KConst make_const(const aoc_problem* p) {
+    return make_const(p->model, p->QQt, p->RRt, p->QQT, p->B, p->T);
+}
+
+static int check_problem(const aoc_problem* p) {
+    if (!p || !p->ref) return AOC_EINVAL;
+    if (p->B < 1 || p->T < 3) return AOC_EINVAL;
+    // R must be symmetric for the 2x2 closed forms used by the gain solve
+    if (p->RRt[1] != p->RRt[2]) return AOC_EINVAL;
+    return AOC_OK;
+}
+
+extern "C" {
+
+const char* aoc_version(void) { return "aoc-hip 0.1 (gfx950)"; }
+
+const char* aoc_strerror(int code) {
+    switch (code) {
+        case AOC_OK: return "ok";
+        case AOC_EINVAL: return "invalid argument";
+        case AOC_ELAUNCH: return "HIP launch/runtime error";
+        case AOC_ENODEV: return "no usable device";
+        default: return "unknown error";
+    }
+}
+
+const char* aoc_last_hip_error(void) { return g_hip_err; }
+
+int32_t aoc_ntiles(int32_t B) { return (B + TILE - 1) / TILE; }
+
+size_t aoc_tiled_elems(int32_t B, int32_t T, int32_t C) { return (size_t)aoc_ntiles(B) * T * C * TILE; }
+
+int aoc_pack(int32_t B, int32_t T, int32_t C, const double* src, double* dst, void* stream) {
+    if (!src || !dst || B < 1 || T < 1 || C < 1) return AOC_EINVAL;
+    dim3 grid(aoc_ntiles(B), T < 64 ? T : 64);
+    hipLaunchKernelGGL(k_pack, grid, dim3(TILE), 0, (hipStream_t)stream, B, T, C, src, dst);
+    return check_launch("k_pack");
+}
+
+int aoc_unpack(int32_t B, int32_t T, int32_t C, const double* src, double* dst, void* stream) {
+    if (!src || !dst || B < 1 || T < 1 || C < 1) return AOC_EINVAL;
+    dim3 grid(aoc_ntiles(B), T < 64 ? T : 64);
+    hipLaunchKernelGGL(k_unpack, grid, dim3(TILE), 0, (hipStream_t)stream, B, T, C, src, dst);
+    return check_launch("k_unpack");
+}
+
+int aoc_step_batch(const aoc_model* model, int32_t n, const double* x, const double* u, const double* lmbd,
+                   double* xp, double* fx, double* fu, double* fxx, double* fuu, double* fux, void* stream) {
+    if (!model || !x || !u || !xp || n < 1) return AOC_EINVAL;
+    KConst k = make_const(*model, nullptr, nullptr, nullptr, n, 3);
+    hipLaunchKernelGGL(k_step_batch, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, k, n, x, u, lmbd, xp,
+                       fx, fu, fxx, fuu, fux);
+    return check_launch("k_step_batch");
+}
+
+int aoc_cost_batch(const aoc_problem* prob, int32_t n, const double* x, const double* u, const double* xr,
+                   const double* ur, double* ll, double* lx, double* lu, double* llT, double* lTx, void* stream) {
+    if (!prob || !x || !u || !xr || !ur || n < 1) return AOC_EINVAL;
+    KConst k = make_const(prob->model, prob->QQt, prob->RRt, prob->QQT, n, 3);
+    if (k.diag)
+        hipLaunchKernelGGL(k_cost_batch<true>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, k, n, x, u, xr,
+                           ur, ll, lx, lu, llT, lTx);
+    else
+        hipLaunchKernelGGL(k_cost_batch<false>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, k, n, x, u, xr,
+                           ur, ll, lx, lu, llT, lTx);
+    return check_launch("k_cost_batch");
+}
+
+int aoc_traj_cost(const aoc_problem* p, const double* x, const double* u, double* J) {
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (!x || !u || !J) return AOC_EINVAL;
+    KConst k = make_const(p);
+    hipStream_t st = (hipStream_t)p->stream;
+    if (k.diag) hipLaunchKernelGGL(k_traj_cost<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, x, u, J);
+    else hipLaunchKernelGGL(k_traj_cost<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, x, u, J);
+    return check_launch("k_traj_cost");
+}
+
+int aoc_rollout_cost(const aoc_problem* p, const double* x0, const double* u, const double* du,
+                     const double* alpha, double* x_out, double* u_out, double* J_out, int32_t* status) {
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (!x0 || !u || !J_out) return AOC_EINVAL;
+    if ((x_out == nullptr) != (u_out == nullptr)) return AOC_EINVAL;
+    if (du && !alpha) return AOC_EINVAL;
+    KConst k = make_const(p);
+    hipStream_t st = (hipStream_t)p->stream;
+    const bool w = x_out != nullptr;
+#define LAUNCH_RC(D, W)                                                                                         \
+    hipLaunchKernelGGL((k_rollout_cost<D, W>), dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, x0, u, du, alpha, \
+                       x_out, u_out, J_out, status)
+    if (k.diag) { if (w) LAUNCH_RC(true, true); else LAUNCH_RC(true, false); }
+    else { if (w) LAUNCH_RC(false, true); else LAUNCH_RC(false, false); }
+#undef LAUNCH_RC
+    return check_launch("k_rollout_cost");
+}
+
+int aoc_backward(const aoc_problem* p, int32_t full_hessian, const double* x, const double* u, double* Kt,
+                 double* g, double* lmbd0, int32_t* status) {
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (!x || !u || !Kt || !g) return AOC_EINVAL;
+    KConst k = make_const(p);
+    hipStream_t st = (hipStream_t)p->stream;
+#define LAUNCH_BW(D, F) \
+    hipLaunchKernelGGL((k_backward<D, F>), dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, x, u, Kt, g, lmbd0, status)
+    if (k.diag) { if (full_hessian) LAUNCH_BW(true, true); else LAUNCH_BW(true, false); }
+    else { if (full_hessian) LAUNCH_BW(false, true); else LAUNCH_BW(false, false); }
+#undef LAUNCH_BW
+    return check_launch("k_backward");
+}
+
+int aoc_forward(const aoc_problem* p, double alpha0, const double* x, const double* u, const double* x0,
+                const double* Kt, const double* g, double* du, double* descent, double* x_new, double* u_new,
+                double* J_new, int32_t* status) {
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (!x || !u || !x0 || !Kt || !g || !du || !descent || !x_new || !u_new || !J_new) return AOC_EINVAL;
+    KConst k = make_const(p);
+    hipStream_t st = (hipStream_t)p->stream;
+    if (k.diag)
+        hipLaunchKernelGGL(k_forward<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, alpha0, p->ref, x, u, x0, Kt, g, du,
+                           descent, x_new, u_new, J_new, status);
+    else
+        hipLaunchKernelGGL(k_forward<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, alpha0, p->ref, x, u, x0, Kt, g,
+                           du, descent, x_new, u_new, J_new, status);
+    return check_launch("k_forward");
+}
+
+int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, const double* u, const double* x0, const double* du,
+                   const double* J_cur, const double* descent, double* x_new, double* u_new, double* J_new,
+                   double* stepsize, int32_t* ntrials, int32_t* status) {
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (!prm || !u || !x0 || !du || !J_cur || !descent || !x_new || !u_new || !J_new || !stepsize || !ntrials)
+        return AOC_EINVAL;
+    if (prm->armijo_maxiters < 1) return AOC_EINVAL;
+    KConst k = make_const(p);
+    hipStream_t st = (hipStream_t)p->stream;
+    if (k.diag)
+        hipLaunchKernelGGL(k_linesearch<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du, J_cur,
+                           descent, x_new, u_new, J_new, stepsize, ntrials, status);
+    else
+        hipLaunchKernelGGL(k_linesearch<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du, J_cur,
+                           descent, x_new, u_new, J_new, stepsize, ntrials, status);
+    return check_launch("k_linesearch");
+}
+
+size_t aoc_workspace_bytes(int32_t B, int32_t T) {
+    // K~ (14) + g (2) + du (2) components, tiled
+    return aoc_tiled_elems(B, T, 18) * sizeof(double);
+}
+
+int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, const double* x, const double* u,
+                       const double* x0, const double* J_cur, void* workspace, double* x_new, double* u_new,
+                       double* J_new, double* descent, double* stepsize, int32_t* ntrials, int32_t* status) {
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (!prm || !workspace) return AOC_EINVAL;
+    double* Kt = (double*)workspace;
+    double* g = Kt + aoc_tiled_elems(p->B, p->T, 14);
+    double* du = g + aoc_tiled_elems(p->B, p->T, 2);
+    rc = aoc_backward(p, kk > prm->hessian_switch, x, u, Kt, g, nullptr, status);
+    if (rc) return rc;
+    rc = aoc_forward(p, prm->stepsize_0, x, u, x0, Kt, g, du, descent, x_new, u_new, J_new, status);
+    if (rc) return rc;
+    return aoc_linesearch(p, prm, u, x0, du, J_cur, descent, x_new, u_new, J_new, stepsize, ntrials, status);
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+/*
+ * aoc.h — C-ABI of libaoc_hip.so: batched Newton/LQR trajectory optimiser for the 6-state /
+ * 2-input planar aircraft, hand-written HIP for MI355X (gfx950).
+ *
+ * The reference (MohamedAtwan/AirCraftOptimalControl) is pure Python and has no FFI; the boundary
+ * this library replaces is its Python call surface, cited per entry point below as file:line of
+ * the reference.  Every entry point takes plain pointers and sizes only.
+ *
+ * Conventions
+ *   - All array pointers are DEVICE pointers (HBM), allocated and owned by the caller; the
+ *     library keeps no pointer after a call returns and allocates nothing.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue work
+ *     on that stream and return; they do not synchronise.
+ *   - Return value: AOC_OK (0) or a negative AOC_E* code; aoc_strerror() names it.  Numerical
+ *     trouble of individual trajectories is reported in the per-trajectory `status` words, never by
+ *     the return value.
+ *
+ * Device ("tiled") trajectory layout
+ *   A batch of B trajectories is cut into tiles of AOC_TILE = 64 consecutive trajectories (one
+ *   wavefront each); ntiles = ceil(B/64).  A trajectory array with C components and T samples is
+ *       elem(b, t, c)  at  (((b/64)*T + t)*C + c)*64 + (b%64)            [fp64]
+ *   i.e. [tile][t][component][lane], lane fastest, so that one wavefront reads/writes 512
+ *   contiguous bytes per (t, component) and walks its own contiguous slab over the horizon.
+ *   aoc_pack()/aoc_unpack() convert from/to the reference's per-trajectory (C,T) C-order arrays
+ *   stacked as (B,C,T).  Lanes of the last tile beyond B replicate trajectory B-1.
+ *   Per-trajectory scalars are plain arrays of length ntiles*64.
+ */
+#ifndef AOC_H
+#define AOC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AOC_TILE 64
+#define AOC_NS 6
+#define AOC_NI 2
+
+enum {
+    AOC_OK = 0,
+    AOC_EINVAL = -1,   /* bad argument (NULL pointer, B/T out of range, ...) */
+    AOC_ELAUNCH = -2,  /* HIP launch / runtime error; see aoc_last_hip_error() */
+    AOC_ENODEV = -3    /* no usable gfx950 device */
+};
+
+/* per-trajectory status bit flags (SURVEY 8b "error conventions") */
+enum {
+    AOC_ST_NAN = 1,          /* NaN/Inf met in cost or descent */
+    AOC_ST_VNONPOS = 2,      /* V <= 0 met in a rollout (division by V, aircraft_simplified.py:310) */
+    AOC_ST_SINGULAR = 4,     /* det(M) == 0 (np.linalg.inv would raise, optcon.py:728/:751) */
+    AOC_ST_REGULARISED = 8,  /* M + 0.5 I applied at some stage (optcon.py:745-749) */
+    AOC_ST_ARMIJO_EXH = 16,  /* line search exhausted; untested step applied (optcon.py:243-273) */
+    AOC_ST_CONVERGED = 32    /* descent >= term_cond reached (optcon.py:499) */
+};
+
+/* aircraft_simplified.py:108-118 (Dynamics.__init__) */
+typedef struct aoc_model {
+    double cd0, cda, cla, m, g, S, rho, J, dt;
+} aoc_model;
+
+/* Problem = Dynamics constants + Cost(QQt,RRt,QQT) (aircraft_simplified.py:20-23) + reference
+ * curves (NewtonMethod.__init__ xx_ref/uu_ref, optcon.py:335-339) + batch geometry. */
+typedef struct aoc_problem {
+    aoc_model model;
+    double QQt[36];   /* row-major 6x6 */
+    double RRt[4];    /* row-major 2x2 */
+    double QQT[36];   /* row-major 6x6 */
+    int32_t B;        /* trajectories */
+    int32_t T;        /* samples per trajectory = int(tf/dt), optcon.py:378 (T-1 stages) */
+    const double *ref;/* DEVICE, shared by the batch, time-major [T][8]: xx_ref[0..5,t], uu_ref[0..1,t] */
+    void *stream;     /* hipStream_t */
+} aoc_problem;
+
+/* Solver parameters = NewtonMethod constructor arguments (optcon.py:335-339) plus the two constants
+ * the reference hard-codes. */
+typedef struct aoc_params {
+    int32_t max_iters;       /* optcon.py:367 */
+    int32_t armijo_maxiters; /* optcon.py:230 */
+    double stepsize_0;       /* optcon.py:224 */
+    double cc;               /* optcon.py:227 */
+    double beta;             /* optcon.py:229 */
+    double term_cond;        /* -1e-6 hard-coded at optcon.py:368 (constructor value is ignored) */
+    int32_t hessian_switch;  /* 8: full Hessian when kk > 8, optcon.py:443 */
+    int32_t reserved;
+} aoc_params;
+
+const char *aoc_version(void);
+const char *aoc_strerror(int code);
+const char *aoc_last_hip_error(void);
+/* number of doubles in a tiled array of C components: ntiles*T*C*64 */
+size_t aoc_tiled_elems(int32_t B, int32_t T, int32_t C);
+int32_t aoc_ntiles(int32_t B);
+
+/* (B,C,T) C-order  <->  tiled.  Replaces nothing in the reference: it is the price of the batch
+ * layout.  src/dst are device pointers. */
+int aoc_pack(int32_t B, int32_t T, int32_t C, const double *src_bct, double *dst_tiled, void *stream);
+int aoc_unpack(int32_t B, int32_t T, int32_t C, const double *src_tiled, double *dst_bct, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Unit level
+ * --------------------------------------------------------------------------------------------- */
+
+/* Dynamics.step(xx,uu[,lmbd])  (aircraft_simplified.py:263-393), n independent points.
+ * x (n,6), u (n,2), lmbd (n,6) or NULL; outputs (any may be NULL except xp): xp (n,6) [fp64 values
+ * rounded to float32, :300], fx (n,6,6) = A^T, fu (n,2,6) = B^T, and when lmbd != NULL the
+ * contracted fxx (n,6,6), fuu (n,2,2), fux (n,2,6)  (:384-388). */
+int aoc_step_batch(const aoc_model *model, int32_t n, const double *x, const double *u, const double *lmbd,
+                   double *xp, double *fx, double *fu, double *fxx, double *fuu, double *fux, void *stream);
+
+/* Cost.stagecost / Cost.termcost (aircraft_simplified.py:25-97), n independent points.
+ * x,xr (n,6); u,ur (n,2).  ll (n), lx (n,6), lu (n,2); llT (n), lTx (n,6).  Any output may be NULL. */
+int aoc_cost_batch(const aoc_problem *prob, int32_t n, const double *x, const double *u, const double *xr,
+                   const double *ur, double *ll, double *lx, double *lu, double *llT, double *lTx, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pass level (tiled layout).  One call = one pass over the horizon for the whole batch.
+ * --------------------------------------------------------------------------------------------- */
+
+/* Cost of a stored trajectory: the loop at optcon.py:417-424.  J[ntiles*64]. */
+int aoc_traj_cost(const aoc_problem *prob, const double *x, const double *u, double *J);
+
+/* get_update (optcon.py:176-200) fused with the cost loop of one Armijo trial (optcon.py:250-264):
+ * u' = u + alpha[b]*du, x' rolled out from x0 with the float32 state rounding, J' accumulated.
+ * x0 [ntiles][6][64]; alpha, J_out [ntiles*64]; du may be NULL (alpha ignored: plain rollout of u).
+ * x_out/u_out may be NULL (cost only).  status is OR-ed. */
+int aoc_rollout_cost(const aoc_problem *prob, const double *x0, const double *u, const double *du,
+                     const double *alpha, double *x_out, double *u_out, double *J_out, int32_t *status);
+
+/* Backward pass of one Newton iteration: terminal condition, costate sweep, quadratisation
+ * (Gauss-Newton or full Hessian) and the affine Riccati/gain recursion of ltv_LQR, fused
+ * (optcon.py:429-464 + :655-751).  Writes per stage the gain K~ (2x7: column 0 feed-forward sigma,
+ * columns 1..6 feedback K) as 14 components and g = B^T lambda_{t+1} + r (2 components).
+ * Kt: tiled C=14 over T samples (sample T-1 unused), g: tiled C=2.
+ * lmbd0 (optional, [ntiles][6][64]) receives lambda_0. */
+int aoc_backward(const aoc_problem *prob, int32_t full_hessian, const double *x, const double *u,
+                 double *Kt, double *g, double *lmbd0, int32_t *status);
+
+/* Forward pass: closed-loop linear rollout of ltv_LQR (optcon.py:756-762) giving du, the descent
+ * sum (optcon.py:474-477), fused with the first Armijo trial (step alpha0 = stepsize_0): u' = u +
+ * alpha0*du, nonlinear rollout x' from x0, cost J' (optcon.py:250-264).
+ * Outputs: du (tiled C=2), descent[ntiles*64], x_new/u_new (tiled), J_new[ntiles*64]. */
+int aoc_forward(const aoc_problem *prob, double alpha0, const double *x, const double *u, const double *x0,
+                const double *Kt, const double *g, double *du, double *descent, double *x_new,
+                double *u_new, double *J_new, int32_t *status);
+
+/* Armijo back-tracking after the first trial (optcon.py:243-273) and the final update
+ * (optcon.py:488-491).  For every trajectory: if J_new <= J_cur + cc*alpha0*descent the first trial
+ * is accepted and (x_new,u_new,J_new) are left as written by aoc_forward.  Otherwise trials
+ * ii = 1 .. armijo_maxiters-1 are rolled out (cost only) until accepted; on exhaustion the untested
+ * step stepsize_0*beta^armijo_maxiters is used (Q5); then the accepted step is rolled out into
+ * x_new/u_new and J_new is its cost.  stepsize[b], ntrials[b] report the result. */
+int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, const double *u, const double *x0,
+                   const double *du, const double *J_cur, const double *descent, double *x_new,
+                   double *u_new, double *J_new, double *stepsize, int32_t *ntrials, int32_t *status);
+
+/* ---------------------------------------------------------------------------------------------
+ * Iteration level.  Workspace: caller-allocated device memory of aoc_workspace_bytes(B,T) bytes.
+ * --------------------------------------------------------------------------------------------- */
+size_t aoc_workspace_bytes(int32_t B, int32_t T);
+
+/* One outer iteration kk of NewtonMethod.optimize for every trajectory (optcon.py:415-491, steps
+ * A-G of SURVEY 3.2): backward, forward, line search.  (x,u) current iterate, J_cur its cost
+ * (from aoc_traj_cost for kk = 0, J_new of the previous iteration afterwards — the reference
+ * recomputes the same number, optcon.py:417-424).  Results: x_new,u_new,J_new and the
+ * per-trajectory scalars descent, stepsize, ntrials.  No trajectory is skipped (fixed-iteration
+ * mode); convergence bookkeeping is the caller's (aoc_newton_solve does it). */
+int aoc_newton_iterate(const aoc_problem *prob, const aoc_params *prm, int32_t kk, const double *x,
+                       const double *u, const double *x0, const double *J_cur, void *workspace,
+                       double *x_new, double *u_new, double *J_new, double *descent, double *stepsize,
+                       int32_t *ntrials, int32_t *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AOC_H */

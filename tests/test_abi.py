@@ -1,0 +1,51 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/aoc.h declares, struct sizes agree, and argument errors are reported (no compute)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from aircraftoptimalcontrol_amd import _lib
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "aoc.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(aoc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    _lib.build_library()
+    lib = _lib.lib()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "libaoc_hip.so does not export %s" % n
+        assert n in _lib.SYMBOLS, "python binding misses %s" % n
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_geometry_helpers_and_errors():
+    lib = _lib.lib()
+    assert lib.aoc_ntiles(1) == 1 and lib.aoc_ntiles(64) == 1 and lib.aoc_ntiles(65) == 2
+    assert lib.aoc_tiled_elems(100, 500, 6) == 2 * 500 * 6 * 64
+    assert lib.aoc_workspace_bytes(64, 500) == 64 * 500 * 18 * 8
+    assert b"gfx950" in lib.aoc_version()
+    assert lib.aoc_strerror(-1) == b"invalid argument"
+    # struct layout must match the header: 9 doubles + 76 doubles + 2 int32 + 2 pointers
+    assert C.sizeof(_lib.Model) == 72
+    assert C.sizeof(_lib.Problem) == 72 + 76 * 8 + 8 + 16
+    assert C.sizeof(_lib.Params) == 48
+    # argument errors are reported before anything touches a device
+    p = _lib.Problem()
+    assert lib.aoc_traj_cost(C.byref(p), None, None, None) == -1
+    assert lib.aoc_pack(0, 10, 6, None, None, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_SO", "/nonexistent/libaoc_hip.so")
+    with pytest.raises(_lib.AocError):
+        _lib.lib()

@@ -1,0 +1,287 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle and the golden vectors captured
+from the reference.  Needs a real MI355X: run with  -m gpu.
+
+Tolerances: unit quantities 1e-12 rel; gains/direction/iterates 1e-8 rel; rollouts with
+the reference's float32 state rounding bit-exact.  The float32 rounding makes whole-trajectory
+comparison discontinuous: a last-bit difference in u can flip one rounding and move every later
+state by an fp32 ulp.  Chains are therefore checked both free-running and "teacher-forced" (every
+iteration restarted from the golden iterate), and flips — if any — are counted, not hidden."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aoc():
+    from aircraftoptimalcontrol_amd import batch
+    return batch
+
+
+def scaled_err(K, Kref, axis=-1):
+    sc = np.abs(Kref).max(axis=axis, keepdims=True)
+    return float(np.max(np.abs(K - Kref) / np.maximum(sc, 1e-300)))
+
+
+def _problem(aoc, name):
+    g = load_golden(name)
+    bp = aoc.BatchProblem(g["QQt"], g["RRt"], g["QQT"], g["xx_ref"], g["uu_ref"], float(g["dt"]))
+    op = orc.OracleProblem(g["QQt"], g["RRt"], g["QQT"], g["xx_ref"], g["uu_ref"], float(g["dt"]))
+    return g, bp, op
+
+
+# ----------------------------------------------------------------------------------------------
+# unit level: D1 (Dynamics.step), C1/C2 (Cost)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [1e-3, 2e-3])
+def test_step_batch_vs_golden(aoc, dt):
+    g = load_golden("g1_step_dt%g" % dt)
+    xp, fx, fu, fxx, fuu, fux = aoc.step_batch(aoc.default_model(dt), g["x"], g["u"], g["lmbd"])
+    assert np.array_equal(xp.astype(np.float32), g["xp"])  # fp32-rounded next state: bit-exact
+    assert rel_err(fx, g["fx"], 1e-12) < 1e-12
+    assert rel_err(fu, g["fu"], 1e-12) < 1e-12
+    assert scaled_err(fxx.reshape(-1, 36), g["fxx"].reshape(-1, 36)) < 1e-12
+    assert scaled_err(fux.reshape(-1, 12), g["fux"].reshape(-1, 12)) < 1e-12
+    assert not fuu.any()
+
+
+def test_step_batch_vs_oracle_random(aoc):
+    rng = np.random.default_rng(7)
+    n = 4096
+    X = np.stack([rng.uniform(-5, 20, n), rng.uniform(-3, 5, n), rng.uniform(9, 23, n),
+                  rng.uniform(-1.5, 1.5, n), rng.uniform(-25, 25, n), rng.uniform(-1.5, 1.5, n)], 1)
+    U = np.stack([rng.uniform(0, 900, n), rng.uniform(-100, 300, n)], 1)
+    mdl = orc.default_model(2e-3)
+    xp = aoc.step_batch(aoc.default_model(2e-3), X, U)[0]
+    ref = np.stack([orc.step(mdl, X[i], U[i])[0] for i in range(n)])
+    assert np.array_equal(xp, ref)
+
+
+@pytest.mark.parametrize("tag", ["step", "acro"])
+def test_cost_batch_vs_golden(aoc, tag):
+    g = load_golden("g2_cost_" + tag)
+    bp = aoc.BatchProblem(g["QQt"], g["RRt"], g["QQT"], np.zeros((6, 4)), np.zeros((2, 4)), 1e-3)
+    ll, lx, lu, llT, lTx = aoc.cost_batch(bp, g["x"], g["u"], g["xr"], g["ur"])
+    assert np.allclose(ll, g["ll"], rtol=1e-13, atol=0) and np.allclose(llT, g["llT"], rtol=1e-13, atol=0)
+    assert rel_err(lx, g["lx"], 1e-12) < 1e-13 and rel_err(lu, g["lu"], 1e-12) < 1e-13
+    assert rel_err(lTx, g["lTx"], 1e-12) < 1e-13
+
+
+def test_cost_batch_dense_weights(aoc):
+    """Cost accepts general dense Q/R (aircraft_simplified.py:61); exercised vs the oracle."""
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(6, 6)); Q = A @ A.T
+    Bm = rng.normal(size=(2, 2)); R = Bm @ Bm.T
+    A2 = rng.normal(size=(6, 6)); QT = A2 @ A2.T
+    bp = aoc.BatchProblem(Q, R, QT, np.zeros((6, 4)), np.zeros((2, 4)), 1e-3)
+    op = orc.OracleProblem(Q, R, QT, np.zeros((6, 4)), np.zeros((2, 4)), 1e-3)
+    n = 100
+    x, xr = rng.normal(size=(n, 6)), rng.normal(size=(n, 6))
+    u, ur = rng.normal(size=(n, 2)), rng.normal(size=(n, 2))
+    ll, lx, lu, llT, lTx = aoc.cost_batch(bp, x, u, xr, ur)
+    for i in range(n):
+        l0, lx0, lu0 = orc.stagecost(op, x[i], u[i], xr[i], ur[i])
+        lT0, lTx0 = orc.termcost(op, x[i], xr[i])
+        assert abs(ll[i] - l0) <= 1e-13 * abs(l0) and abs(llT[i] - lT0) <= 1e-13 * abs(lT0)
+        assert np.allclose(lx[i], lx0, rtol=1e-12, atol=1e-14) and np.allclose(lTx[i], lTx0, rtol=1e-12, atol=1e-14)
+
+
+def test_pack_unpack_roundtrip(aoc):
+    import torch
+    rng = np.random.default_rng(0)
+    for B in (1, 63, 64, 65, 200):
+        a = rng.normal(size=(B, 6, 37))
+        t = aoc.pack(a)
+        assert tuple(t.shape) == (aoc.ntiles(B), 37, 6, 64)
+        assert np.array_equal(aoc.unpack(t, B).cpu().numpy(), a)
+        # padded lanes replicate trajectory B-1
+        if B % 64:
+            assert torch.equal(t[-1, :, :, B % 64:], t[-1, :, :, (B % 64) - 1:(B % 64)].expand(-1, -1, 64 - B % 64))
+
+
+# ----------------------------------------------------------------------------------------------
+# pass level: A1/A2 rollout + cost, N1-C/L1 backward + forward
+# ----------------------------------------------------------------------------------------------
+def test_rollout_cost_vs_oracle(aoc):
+    g, bp, op = _problem(aoc, "problem_step_T500")
+    c = load_golden("g6_chain_step_T500")
+    rng = np.random.default_rng(11)
+    B = 96
+    uu = np.repeat(c["uu_it3"][None], B, 0) + rng.normal(0, 1.0, (B, 2, 500))
+    du = rng.normal(0, 1.0, (B, 2, 500))
+    x0 = c["xx_init"][:, 0][None] + rng.normal(0, 0.1, (B, 6))
+    alpha = 0.7 ** rng.integers(0, 10, B)
+    xx, un, J, st = aoc.rollout_cost(bp, x0, uu, du, alpha)
+    flips = 0
+    for b in range(B):
+        xo, uo = orc.get_update(op, alpha[b], uu[b], du[b], x0[b])
+        Jo = orc.traj_cost(op, xo, uo)
+        assert np.array_equal(un[b], uo)
+        flips += int(not np.array_equal(xx[b], xo))
+        if np.array_equal(xx[b], xo):
+            assert J[b] == Jo
+    assert flips == 0, "fp32-rounded rollouts must be bit-identical (%d of %d differ)" % (flips, B)
+    assert not st.any()
+    # cost-only variant and the stored-trajectory cost agree with the rollout's own cost
+    _, _, J2, _ = aoc.rollout_cost(bp, x0, uu, du, alpha, write=False)
+    assert np.array_equal(J, J2)
+    assert np.array_equal(aoc.traj_cost(bp, xx, un), J)
+
+
+LQR_CASES = [("a_gn_init_T1000", "problem_step_T1000", 1e-8), ("b_full_init_T1000", "problem_step_T1000", 1e-5),
+             ("c_full_near_T500", "problem_step_T500", 1e-8), ("d_gn_init_T500", "problem_step_T500", 1e-8)]
+
+
+@pytest.mark.parametrize("case,prob,tol", LQR_CASES)
+def test_backward_forward_vs_golden(aoc, case, prob, tol):
+    """Fused backward pass (costate + quadratisation + Riccati + gains) and LQR rollout against the
+    reference's ltv_LQR outputs, incl. the regularisation branch (case b: 18 stages)."""
+    g = load_golden("g3_lqr_" + case)
+    _, bp, op = _problem(aoc, prob)
+    fh = int(g["full_hessian"])
+    r = aoc.backward_forward(bp, g["xx"][None], g["uu"][None], fh)
+    KK = r["KK"][0]
+    assert scaled_err(KK[:, :, :-1], g["KK"][:, :, :-1]) < tol
+    assert rel_err(r["du"][0], g["du"], 1e-3) < tol
+    assert abs(r["descent"][0] - float(g["descent"])) <= tol * abs(float(g["descent"]))
+    assert rel_err(r["lmbd0"][0], g["lmbd"][:, 0], 1e-9) < 1e-9
+    from aircraftoptimalcontrol_amd import _lib
+    assert bool(r["status"][0] & _lib.ST_REGULARISED) == (int(g["n_regularised"]) > 0)
+    # first Armijo trial = get_update(stepsize_0) of the oracle on the reference's du
+    xo, uo = orc.get_update(op, 1.0, g["uu"], g["du"], g["xx"][:, 0])
+    assert rel_err(r["uu_new"][0], uo, 1e-3) < tol
+
+
+# ----------------------------------------------------------------------------------------------
+# iteration level: N1 (optimize), A1 (armijo), chains
+# ----------------------------------------------------------------------------------------------
+CHAINS = [("g6_chain_step_T500", "problem_step_T500"), ("g6_chain_step_T1000", "problem_step_T1000"),
+          ("g6_chain_acro_T1000", "problem_acro_T1000")]
+
+
+def _flip_aware_compare(xx, uu, gx, gu, tag):
+    """-> True if clean (xx bit-identical, uu within 1e-8); otherwise asserts the deviation is of
+    fp32-rounding-flip size (states within a few fp32 ulps) and returns False."""
+    if np.array_equal(xx, gx):
+        assert rel_err(uu, gu, 1e-3) < 1e-8, tag
+        return True
+    assert rel_err(xx, gx, 1e-2) < 5e-6, "%s: state deviation larger than fp32 rounding flips" % tag
+    return False
+
+
+@pytest.mark.parametrize("chain,prob", CHAINS)
+def test_chain_teacher_forced(aoc, chain, prob):
+    """Every stored golden iterate k -> k+1 with one HIP Newton iteration started from the GOLDEN
+    iterate k: Armijo step, trial count, cost, descent and the new iterate."""
+    g, bp, op = _problem(aoc, prob)
+    c = load_golden(chain)
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    keys = sorted(int(k[5:]) for k in c if k.startswith("xx_it"))
+    pairs = [(0, 1)] + [(k, k + 1) for k in keys if k + 1 in keys]
+    flips = 0
+    for k0, k1 in pairs:
+        xx = c["xx_init"] if k0 == 0 else c["xx_it%d" % k0]
+        uu = c["uu_init"] if k0 == 0 else c["uu_it%d" % k0]
+        s = aoc.NewtonBatchSolver(bp, 1, prm)
+        xi = xx[None].copy(); xi[0, :, 0] = c["xx_init"][:, 0]
+        s.set_initial(xi, uu[None])
+        s.iterate(k0)
+        sc = s.scalars()
+        assert abs(sc["cost"][0] - c["cost"][k0]) <= 1e-10 * abs(c["cost"][k0]), k0
+        assert abs(sc["descent"][0] - c["descent"][k0]) <= 1e-8 * abs(c["descent"][k0]), k0
+        assert sc["stepsize"][0] == c["stepsize"][k0], k0
+        assert sc["ntrials"][0] == c["ntrials"][k0], k0
+        xn, un = s.current()
+        flips += int(not _flip_aware_compare(xn[0], un[0], c["xx_it%d" % k1], c["uu_it%d" % k1], "iter %d" % k0))
+    assert flips == 0, "%d of %d iterations showed an fp32 rounding flip" % (flips, len(pairs))
+
+
+@pytest.mark.parametrize("chain,prob", CHAINS)
+def test_chain_free_running(aoc, chain, prob):
+    g, bp, op = _problem(aoc, prob)
+    c = load_golden(chain)
+    n = int(c["n_done"])
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    s = aoc.NewtonBatchSolver(bp, 1, prm)
+    s.set_initial(c["xx_init"][None], c["uu_init"][None])
+    clean = True
+    for kk in range(n):
+        s.iterate(kk)
+        sc = s.scalars()
+        if clean:
+            assert abs(sc["cost"][0] - c["cost"][kk]) <= 1e-10 * abs(c["cost"][kk]), kk
+            assert abs(sc["descent"][0] - c["descent"][kk]) <= 1e-8 * abs(c["descent"][kk]), kk
+            assert sc["stepsize"][0] == c["stepsize"][kk], kk
+        else:  # after a flip only the cost trace is comparable (rel 1e-6)
+            assert abs(sc["cost"][0] - c["cost"][kk]) <= 1e-6 * abs(c["cost"][kk]), kk
+        key = "xx_it%d" % (kk + 1)
+        if key in c and clean:
+            xn, un = s.current()
+            clean = _flip_aware_compare(xn[0], un[0], c[key], c["uu_it%d" % (kk + 1)], "iter %d" % kk)
+    assert clean, "free-running chain left the bit-exact path (fp32 flip) before iteration %d" % n
+
+
+def test_minibatch_g9_and_lane_independence(aoc):
+    """Config-2 generation rule mini-batch (perturbed x0): 4 iterations, all trajectories in ONE
+    launch, plus: results do not depend on the lane/tile a trajectory sits in."""
+    g, bp, op = _problem(aoc, "problem_step_T500")
+    m = load_golden("g9_minibatch_step_T500")
+    n = int(m["n_iters"])
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    Bm = m["xx_init"].shape[0]
+    reps = 9  # 72 trajectories -> two tiles, second one ragged
+    perm = np.random.default_rng(5).permutation(Bm * reps)
+    XI = np.tile(m["xx_init"], (reps, 1, 1))[perm]
+    UI = np.tile(m["uu_init"], (reps, 1, 1))[perm]
+    s = aoc.NewtonBatchSolver(bp, Bm * reps, prm)
+    s.set_initial(XI, UI)
+    hist = s.run_fixed(n)
+    xx, uu = s.current()
+    src = np.tile(np.arange(Bm), reps)[perm]
+    for j in range(Bm * reps):
+        b = src[j]
+        for it in range(n):
+            assert hist[it]["stepsize"][j] == m["stepsize"][b, it]
+            assert abs(hist[it]["cost"][j] - m["cost"][b, it]) <= 1e-10 * abs(m["cost"][b, it])
+            assert abs(hist[it]["descent"][j] - m["descent"][b, it]) <= 1e-8 * abs(m["descent"][b, it])
+        assert np.array_equal(xx[j, :, 1:].astype(np.float32), m["xx_out"][b, :, 1:])
+        assert rel_err(uu[j], m["uu_out"][b], 1e-3) < 1e-8
+    # identical inputs in different lanes give bit-identical outputs
+    for b in range(Bm):
+        idx = np.nonzero(src == b)[0]
+        for j in idx[1:]:
+            assert np.array_equal(uu[j], uu[idx[0]]) and np.array_equal(xx[j], xx[idx[0]])
+
+
+def test_full_solve_termination_and_return_index(aoc):
+    """G8: solve to convergence: 22 iterations, returned iterate is two behind the newest (Q7),
+    uu[:,-1] = uu[:,-2] (Q8), Armijo exhaustion (Q5) at the recorded iterations."""
+    g, bp, op = _problem(aoc, "problem_step_T500")
+    f = load_golden("g8_full_step_T500")
+    prm = aoc.make_params(max_iters=200, stepsize_0=1.0, armijo_maxiters=10)
+    s = aoc.NewtonBatchSolver(bp, 3, prm)
+    s.set_initial(np.repeat(f["xx_init"][None], 3, 0), np.repeat(f["uu_init"][None], 3, 0))
+    r = s.solve()
+    n = int(f["n_done"])
+    h = r["history"]
+    # early iterations (before the fp32 noise floor) must match the reference exactly
+    assert np.array_equal(h["stepsize"][0, :14], f["stepsize"][:14])
+    assert np.array_equal(h["ntrials"][0, :14], f["ntrials"][:14])
+    assert np.allclose(h["cost"][0, :14], f["cost"][:14], rtol=1e-10, atol=0)
+    if np.array_equal(h["stepsize"][0], f["stepsize"]):
+        assert r["iters"][0] == n
+        assert np.array_equal(r["xx_star"][0], f["xx_star"])
+        assert rel_err(r["uu_star"][0], f["uu_star"], 1e-3) < 1e-8
+    else:  # late iterations wander in fp32 noise: iteration count +-, final cost 1e-6
+        assert abs(int(r["iters"][0]) - n) <= 6
+    assert abs(h["cost"][0, -1] - f["cost"][-1]) <= 1e-6 * f["cost"][-1]
+    assert np.array_equal(r["uu_star"][0][:, -1], r["uu_star"][0][:, -2])
+    assert r["converged"].all()
+    from aircraftoptimalcontrol_amd import _lib
+    assert (r["status"] & _lib.ST_CONVERGED).all()
+    assert (r["status"][0] & _lib.ST_ARMIJO_EXH) != 0  # the reference exhausts the line search 4 times here
+    # the three identical trajectories agree bit for bit
+    assert np.array_equal(r["xx_star"][0], r["xx_star"][1]) and np.array_equal(r["uu_star"][0], r["uu_star"][2])
