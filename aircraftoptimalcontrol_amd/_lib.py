@@ -68,6 +68,7 @@ SYMBOLS = {
     "aoc_step_batch": (C.c_int, [_P, _I] + [_P] * 10),
     "aoc_cost_batch": (C.c_int, [_P, _I] + [_P] * 10),
     "aoc_traj_cost": (C.c_int, [_P, _P, _P, _P]),
+    "aoc_initial_trajectory": (C.c_int, [_P, _D, _D, _P, _P, _P]),
     "aoc_rollout_cost": (C.c_int, [_P] * 9),
     "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
     "aoc_forward": (C.c_int, [_P, _D] + [_P] * 11),
@@ -86,6 +87,14 @@ def lib():
         if not os.path.exists(_SO):
             raise AocError("libaoc_hip.so is not built (%s). Run __graft_entry__.build() or "
                            "aircraftoptimalcontrol_amd.build_library(); there is no CPU fallback." % _SO)
+        # torch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one
+        # process do not share devices or allocations, so torch (whose allocator owns the buffers
+        # we are handed) must be loaded first: the dynamic linker then resolves our NEEDED
+        # libamdhip64.so.7 to the copy that is already mapped.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         try:
             l = C.CDLL(_SO)
         except OSError as e:  # e.g. ROCm runtime missing

@@ -210,6 +210,19 @@ class NewtonBatchSolver:
         p = self._p()
         check(lib().aoc_traj_cost(C.byref(p), _ptr(self.xb[0]), _ptr(self.ub[0]), _ptr(self.J[0])), "aoc_traj_cost")
 
+    def set_initial_from_x0(self, x0, kp=5.0, kt=2.5):
+        """Initial guess by the reference's P-controller law (aircraft_simplified.py:134-147) rolled out
+        on the device from x0 (B,6), straight into the iterate buffers."""
+        torch = _torch()
+        dev = self.problem.device
+        self.x0.copy_(pack_vec(x0, dev))
+        p = self._p()
+        check(lib().aoc_initial_trajectory(C.byref(p), float(kp), float(kt), _ptr(self.x0), _ptr(self.xb[0]),
+                                           _ptr(self.ub[0])), "aoc_initial_trajectory")
+        self.cur, self.kk, self.jcur = 0, 0, 0
+        self.status.zero_()
+        check(lib().aoc_traj_cost(C.byref(p), _ptr(self.xb[0]), _ptr(self.ub[0]), _ptr(self.J[0])), "aoc_traj_cost")
+
     def iterate(self, kk=None):
         """One outer iteration (steps A-G of SURVEY 3.2) for every trajectory; asynchronous."""
         if kk is None:
@@ -222,6 +235,38 @@ class NewtonBatchSolver:
                                        _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.descent), _ptr(self.stepsize),
                                        _ptr(self.ntrials), _ptr(self.status)), "aoc_newton_iterate")
         self.cur, self.jcur, self.kk = n, jn, kk + 1
+
+    def iterate_timed(self, kk=None):
+        """Same launches as iterate(), issued pass by pass with HIP events recorded on the launch
+        stream between them.  Returns the four events (start, after backward, after forward, after
+        line search); read them after a synchronize with ev[i].elapsed_time(ev[i+1]) [ms]."""
+        torch = _torch()
+        if kk is None:
+            kk = self.kk
+        p = self._p()
+        prm = self.params
+        c, n = self.cur, (self.cur + 1) % 3
+        jc, jn = self.jcur, 1 - self.jcur
+        nel14 = lib().aoc_tiled_elems(self.B, self.T, 14)
+        nel2 = lib().aoc_tiled_elems(self.B, self.T, 2)
+        Kt, g, du = self.ws[:nel14], self.ws[nel14:nel14 + nel2], self.ws[nel14 + nel2:nel14 + 2 * nel2]
+        st = torch.cuda.current_stream(self.problem.device)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record(st)
+        check(lib().aoc_backward(C.byref(p), int(kk > prm.hessian_switch), _ptr(self.xb[c]), _ptr(self.ub[c]),
+                                 _ptr(Kt), _ptr(g), None, _ptr(self.status)), "aoc_backward")
+        ev[1].record(st)
+        check(lib().aoc_forward(C.byref(p), prm.stepsize_0, _ptr(self.xb[c]), _ptr(self.ub[c]), _ptr(self.x0),
+                                _ptr(Kt), _ptr(g), _ptr(du), _ptr(self.descent), _ptr(self.xb[n]), _ptr(self.ub[n]),
+                                _ptr(self.J[jn]), _ptr(self.status)), "aoc_forward")
+        ev[2].record(st)
+        check(lib().aoc_linesearch(C.byref(p), C.byref(prm), _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
+                                   _ptr(self.J[jc]), _ptr(self.descent), _ptr(self.xb[n]), _ptr(self.ub[n]),
+                                   _ptr(self.J[jn]), _ptr(self.stepsize), _ptr(self.ntrials), _ptr(self.status)),
+              "aoc_linesearch")
+        ev[3].record(st)
+        self.cur, self.jcur, self.kk = n, jn, kk + 1
+        return ev
 
     # -- results ---------------------------------------------------------------------------------
     def current(self, which=0):

@@ -199,6 +199,36 @@ __global__ __launch_bounds__(TILE) void k_rollout_cost(KConst k, const double* _
     if (status && flags) status[b] |= flags;
 }
 
+// Dynamics.get_initial_trajectory (aircraft_simplified.py:126-148): P-controller rollout from x0.
+__global__ __launch_bounds__(TILE) void k_initial_traj(KConst k, double kp, double kt, const double* __restrict__ ref,
+                                                       const double* __restrict__ x0, double* __restrict__ x_out,
+                                                       double* __restrict__ u_out) {
+    const int tile = blockIdx.x, lane = threadIdx.x, T = k.T;
+    double xs[6], xn[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
+        x_out[tix<6>(tile, T, 0, c, lane)] = xs[c];
+    }
+    for (int i = 0; i < T - 1; i++) {
+        const double* xr = ref + (size_t)(i + 1) * 8;
+        double u0, u1;
+        {
+#pragma clang fp contract(off)
+            u0 = kp * ((xs[0] - xr[0]) + (xs[1] - xr[1]));  // :143
+            u1 = kt * ((xs[3] - xr[3]) + (xs[5] - xr[5]));  // :144
+        }
+        const SC s = trig(xs[3], xs[5]);
+        step_state(k, xs, u0, u1, s, xn);
+        u_out[tix<2>(tile, T, i, 0, lane)] = u0;
+        u_out[tix<2>(tile, T, i, 1, lane)] = u1;
+#pragma unroll
+        for (int c = 0; c < 6; c++) { x_out[tix<6>(tile, T, i + 1, c, lane)] = xn[c]; xs[c] = xn[c]; }
+    }
+    u_out[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
+    u_out[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
+}
+
 // Backward pass (see aoc_backward in include/aoc.h).
 template <bool DIAG, bool FULL>
 __global__ __launch_bounds__(TILE) void k_backward(KConst k, const double* __restrict__ ref,
@@ -536,6 +566,15 @@ int aoc_traj_cost(const aoc_problem* p, const double* x, const double* u, double
     if (k.diag) hipLaunchKernelGGL(k_traj_cost<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, x, u, J);
     else hipLaunchKernelGGL(k_traj_cost<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, x, u, J);
     return check_launch("k_traj_cost");
+}
+
+int aoc_initial_trajectory(const aoc_problem* p, double kp, double kt, const double* x0, double* x, double* u) {
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (!x0 || !x || !u) return AOC_EINVAL;
+    KConst k = make_const(p);
+    hipLaunchKernelGGL(k_initial_traj, dim3(k.ntiles), dim3(TILE), 0, (hipStream_t)p->stream, k, kp, kt, p->ref, x0, x, u);
+    return check_launch("k_initial_traj");
 }
 
 int aoc_rollout_cost(const aoc_problem* p, const double* x0, const double* u, const double* du,

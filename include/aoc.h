@@ -122,6 +122,13 @@ int aoc_cost_batch(const aoc_problem *prob, int32_t n, const double *x, const do
 /* Cost of a stored trajectory: the loop at optcon.py:417-424.  J[ntiles*64]. */
 int aoc_traj_cost(const aoc_problem *prob, const double *x, const double *u, double *J);
 
+/* Dynamics.get_initial_trajectory (aircraft_simplified.py:126-148): P-controller rollout
+ *   u_i = [kp((X-Xr)+(Z-Zr)), kt((th-thr)+(ga-gar))] against xx_ref[:, i+1], from x0 ([ntiles][6][64]).
+ * The reference uses kp = 5, kt = 2.5.  Evaluated in fp64 with the float32 state rounding of step();
+ * the reference's own call runs mostly in float32 (it feeds step() its float32 output), so results
+ * agree to ~1e-4 only — this produces an initial GUESS.  x, u tiled outputs. */
+int aoc_initial_trajectory(const aoc_problem *prob, double kp, double kt, const double *x0, double *x, double *u);
+
 /* get_update (optcon.py:176-200) fused with the cost loop of one Armijo trial (optcon.py:250-264):
  * u' = u + alpha[b]*du, x' rolled out from x0 with the float32 state rounding, J' accumulated.
  * x0 [ntiles][6][64]; alpha, J_out [ntiles*64]; du may be NULL (alpha ignored: plain rollout of u).

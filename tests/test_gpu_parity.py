@@ -285,3 +285,20 @@ def test_full_solve_termination_and_return_index(aoc):
     assert (r["status"][0] & _lib.ST_ARMIJO_EXH) != 0  # the reference exhausts the line search 4 times here
     # the three identical trajectories agree bit for bit
     assert np.array_equal(r["xx_star"][0], r["xx_star"][1]) and np.array_equal(r["uu_star"][0], r["uu_star"][2])
+
+
+def test_initial_trajectory_on_device(aoc):
+    """Row 8f-1: the P-controller initial guess rolled out on the device equals the oracle's
+    (fp64 + float32 state rounding) bit for bit, and the reference's own (mostly-float32) to ~1e-4."""
+    g, bp, op = _problem(aoc, "problem_step_T500")
+    m = load_golden("g9_minibatch_step_T500")
+    B = m["x0"].shape[0]
+    s = aoc.NewtonBatchSolver(bp, B, aoc.make_params(stepsize_0=1.0, armijo_maxiters=10))
+    s.set_initial_from_x0(m["x0"])
+    xx, uu = s.current()
+    mdl = orc.default_model(2e-3)
+    for b in range(B):
+        xr = g["xx_ref"].copy(); xr[:, 0] = m["x0"][b]
+        xo, uo = orc.initial_trajectory(mdl, xr)
+        assert np.array_equal(xx[b], xo) and np.array_equal(uu[b], uo)
+        assert rel_err(xx[b], m["xx_init"][b], 1e-2) < 2e-4
