@@ -72,7 +72,8 @@ SYMBOLS = {
     "aoc_rollout_cost": (C.c_int, [_P] * 9),
     "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
     "aoc_forward": (C.c_int, [_P, _D] + [_P] * 11),
-    "aoc_linesearch": (C.c_int, [_P] * 13),
+    "aoc_linesearch_scratch_bytes": (_Z, [_I]),
+    "aoc_linesearch": (C.c_int, [_P] * 14),
     "aoc_workspace_bytes": (_Z, [_I, _I]),
     "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 12),
 }

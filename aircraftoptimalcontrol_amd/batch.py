@@ -179,13 +179,14 @@ class NewtonBatchSolver:
         self.Bp = self.nt * TILE
         self.xb = [alloc_tiled(B, self.T, 6, dev, zero=True) for _ in range(3)]
         self.ub = [alloc_tiled(B, self.T, 2, dev, zero=True) for _ in range(3)]
-        self.ws = torch.empty(lib().aoc_workspace_bytes(self.B, self.T) // 8, dtype=torch.float64, device=dev)
+        self.ws = torch.empty((lib().aoc_workspace_bytes(self.B, self.T) + 7) // 8, dtype=torch.float64, device=dev)
         f = lambda: torch.zeros(self.Bp, dtype=torch.float64, device=dev)
         self.J = [f(), f()]
         self.descent, self.stepsize = f(), f()
         self.ntrials = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         self.status = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         self.x0 = torch.zeros((self.nt, 6, TILE), dtype=torch.float64, device=dev)
+        self.compact_linesearch = True   # False: lock-step variant in iterate_timed (A/B measurements)
         self.cur = 0      # index of the buffer holding the current iterate
         self.kk = 0       # outer-iteration index of the current iterate
         self.jcur = 0
@@ -262,7 +263,8 @@ class NewtonBatchSolver:
         ev[2].record(st)
         check(lib().aoc_linesearch(C.byref(p), C.byref(prm), _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
                                    _ptr(self.J[jc]), _ptr(self.descent), _ptr(self.xb[n]), _ptr(self.ub[n]),
-                                   _ptr(self.J[jn]), _ptr(self.stepsize), _ptr(self.ntrials), _ptr(self.status)),
+                                   _ptr(self.J[jn]), _ptr(self.stepsize), _ptr(self.ntrials), _ptr(self.status),
+                                   _ptr(self.ws[nel14 + 2 * nel2:]) if self.compact_linesearch else None),
               "aoc_linesearch")
         ev[3].record(st)
         self.cur, self.jcur, self.kk = n, jn, kk + 1

@@ -451,6 +451,150 @@ __global__ __launch_bounds__(TILE) void k_linesearch(KConst k, aoc_params prm, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// Compacted Armijo back-tracking.
+//
+// Lock-step back-tracking inside a tile costs max-over-64-lanes trials per wavefront while the mean
+// is ~1.2-2.  Instead the rejected trajectories are compacted, in tile order, over as few
+// wavefronts as possible, one launch per trial round r (all trajectories share the step
+// a_r = stepsize_0*beta^r, optcon.py:240/:270).  A compacted lane gathers its (u, du) elements from
+// its home tile; because the work list is in tile order a wavefront covers a few neighbouring tiles
+// and touches about the same cache lines a coalesced pass over them would.
+//   k_ls_init   : trial-0 verdicts -> bit mask per tile (bit l = lane l still searching)
+//   k_ls_scan   : exclusive prefix sum of popcounts over tiles (one workgroup), mask copy for the round
+//   k_ls_trial  : compacted cost-only rollouts of round r; accepted lanes clear their bit
+//   k_ls_final  : exhausted lanes get the untested step (Q5); every lane rejected at trial 0 is rolled
+//                 out with its accepted step into x_new/u_new (coalesced, masked; optcon.py:488-491)
+// ---------------------------------------------------------------------------------------------
+struct LsScratch {
+    unsigned long long* mask0;  // [ntiles] rejected at trial 0
+    unsigned long long* maskA;  // [ntiles] ping
+    unsigned long long* maskB;  // [ntiles] pong
+    int* prefix;                // [ntiles+1]
+};
+
+__global__ __launch_bounds__(TILE) void k_ls_init(aoc_params prm, const double* __restrict__ J_cur,
+                                                  const double* __restrict__ descent,
+                                                  const double* __restrict__ J_new, double* __restrict__ stepsize,
+                                                  int* __restrict__ ntrials, LsScratch sc) {
+    const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane;
+    const bool rej = armijo_reject(J_new[b], J_cur[b], prm.cc, prm.stepsize_0, descent[b]);
+    const unsigned long long m = __ballot(rej);
+    stepsize[b] = prm.stepsize_0;
+    ntrials[b] = 1;
+    if (lane == 0) { sc.mask0[tile] = m; sc.maskA[tile] = m; }
+}
+
+// one workgroup of 1024 threads; in -> prefix (exclusive, prefix[ntiles] = total), out = copy of in
+__global__ __launch_bounds__(1024) void k_ls_scan(int ntiles, const unsigned long long* __restrict__ in,
+                                                  unsigned long long* __restrict__ out, int* __restrict__ prefix) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += 1024) {
+        const int i = base + tid;
+        unsigned long long m = 0;
+        if (i < ntiles) { m = in[i]; out[i] = m; }
+        const int c = __popcll(m);
+        int incl = c;  // inclusive scan inside the wavefront
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wv; w++) woff += wsum[w];
+        const int carry = carry_s;
+        if (i < ntiles) prefix[i] = carry + woff + incl - c;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (tid == 0) prefix[ntiles] = carry_s;
+}
+
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int rank) {
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) {
+        const unsigned long long low = m & ((1ull << w) - 1ull);
+        const int c = __popcll(low);
+        if (rank >= c) { rank -= c; m >>= w; pos += w; }
+        else m = low;
+    }
+    return pos;
+}
+
+template <bool DIAG>
+__global__ __launch_bounds__(TILE) void k_ls_trial(KConst k, aoc_params prm, double a_r, int round,
+                                                   const double* __restrict__ ref, const double* __restrict__ u,
+                                                   const double* __restrict__ x0, const double* __restrict__ du,
+                                                   const double* __restrict__ J_cur, const double* __restrict__ descent,
+                                                   double* __restrict__ stepsize, int* __restrict__ ntrials,
+                                                   const unsigned long long* __restrict__ mask_in,
+                                                   unsigned long long* __restrict__ mask_out,
+                                                   const int* __restrict__ prefix) {
+    const int count = prefix[k.ntiles];
+    const int first = blockIdx.x * TILE;
+    if (first >= count) return;
+    const int lane = threadIdx.x;
+    const bool valid = first + lane < count;
+    const int j = valid ? first + lane : count - 1;  // idle lanes shadow the last item (loads stay in range)
+    // tile with prefix[tile] <= j < prefix[tile+1]
+    int lo = 0, hi = k.ntiles;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= j) lo = mid; else hi = mid;
+    }
+    const int tile = lo;
+    const int hl = nth_set_bit(mask_in[tile], j - prefix[tile]);  // home lane inside the tile
+    const int b = tile * TILE + hl;
+    double xs[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) xs[c] = x0[((size_t)tile * 6 + c) * TILE + hl];
+    int f2 = 0;
+    const double Jt = rollout<DIAG, false>(k, ref, tile, hl, xs, u, du, a_r, false, nullptr, nullptr, f2);
+    if (valid) {
+        ntrials[b] = round + 1;
+        if (!armijo_reject(Jt, J_cur[b], prm.cc, a_r, descent[b])) {
+            stepsize[b] = a_r;
+            atomicAnd(&mask_out[tile], ~(1ull << hl));
+        }
+    }
+}
+
+template <bool DIAG>
+__global__ __launch_bounds__(TILE) void k_ls_final(KConst k, double a_exhausted, const double* __restrict__ ref,
+                                                   const double* __restrict__ u, const double* __restrict__ x0,
+                                                   const double* __restrict__ du, double* __restrict__ x_new,
+                                                   double* __restrict__ u_new, double* __restrict__ J_new,
+                                                   double* __restrict__ stepsize, int* __restrict__ status,
+                                                   const unsigned long long* __restrict__ mask0,
+                                                   const unsigned long long* __restrict__ mask_left) {
+    const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane;
+    const unsigned long long m0 = mask0[tile];
+    if (m0 == 0ull) return;  // the whole tile accepted the first trial
+    const bool mine = (m0 >> lane) & 1ull;
+    const bool exhausted = (mask_left[tile] >> lane) & 1ull;
+    int flags = 0;
+    double a = stepsize[b];
+    if (exhausted) { a = a_exhausted; flags |= AOC_ST_ARMIJO_EXH; }  // never evaluated (Q5)
+    double xs[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
+    const double Jf = rollout<DIAG, true>(k, ref, tile, lane, xs, u, du, a, mine, x_new, u_new, flags);
+    if (mine) {
+        if (Jf != Jf || Jf - Jf != 0.0) flags |= AOC_ST_NAN;
+        J_new[b] = Jf;
+        stepsize[b] = a;
+        if (status && flags) status[b] |= flags;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side of the C-ABI
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_hip_err[256] = "";
@@ -628,9 +772,14 @@ int aoc_forward(const aoc_problem* p, double alpha0, const double* x, const doub
     return check_launch("k_forward");
 }
 
+size_t aoc_linesearch_scratch_bytes(int32_t B) {
+    const size_t nt = (size_t)aoc_ntiles(B);
+    return 3 * nt * sizeof(unsigned long long) + ((nt + 1 + 1) & ~(size_t)1) * sizeof(int);
+}
+
 int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, const double* u, const double* x0, const double* du,
                    const double* J_cur, const double* descent, double* x_new, double* u_new, double* J_new,
-                   double* stepsize, int32_t* ntrials, int32_t* status) {
+                   double* stepsize, int32_t* ntrials, int32_t* status, void* scratch) {
     int rc = check_problem(p);
     if (rc) return rc;
     if (!prm || !u || !x0 || !du || !J_cur || !descent || !x_new || !u_new || !J_new || !stepsize || !ntrials)
@@ -638,18 +787,47 @@ int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, const double* u,
     if (prm->armijo_maxiters < 1) return AOC_EINVAL;
     KConst k = make_const(p);
     hipStream_t st = (hipStream_t)p->stream;
+    if (!scratch) {  // lock-step variant: one launch, back-tracking inside each tile
+        if (k.diag)
+            hipLaunchKernelGGL(k_linesearch<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du,
+                               J_cur, descent, x_new, u_new, J_new, stepsize, ntrials, status);
+        else
+            hipLaunchKernelGGL(k_linesearch<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du,
+                               J_cur, descent, x_new, u_new, J_new, stepsize, ntrials, status);
+        return check_launch("k_linesearch");
+    }
+    LsScratch sc;
+    sc.mask0 = (unsigned long long*)scratch;
+    sc.maskA = sc.mask0 + k.ntiles;
+    sc.maskB = sc.maskA + k.ntiles;
+    sc.prefix = (int*)(sc.maskB + k.ntiles);
+    hipLaunchKernelGGL(k_ls_init, dim3(k.ntiles), dim3(TILE), 0, st, *prm, J_cur, descent, J_new, stepsize, ntrials, sc);
+    unsigned long long *cur = sc.maskA, *nxt = sc.maskB;
+    double a = prm->stepsize_0;
+    for (int r = 1; r < prm->armijo_maxiters; r++) {
+        a = prm->beta * a;  // optcon.py:270
+        hipLaunchKernelGGL(k_ls_scan, dim3(1), dim3(1024), 0, st, k.ntiles, cur, nxt, sc.prefix);
+        if (k.diag)
+            hipLaunchKernelGGL(k_ls_trial<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, a, r, p->ref, u, x0, du,
+                               J_cur, descent, stepsize, ntrials, cur, nxt, sc.prefix);
+        else
+            hipLaunchKernelGGL(k_ls_trial<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, a, r, p->ref, u, x0, du,
+                               J_cur, descent, stepsize, ntrials, cur, nxt, sc.prefix);
+        unsigned long long* t = cur; cur = nxt; nxt = t;
+    }
+    a = prm->beta * a;  // the step an exhausted search returns without evaluating it (optcon.py:327)
     if (k.diag)
-        hipLaunchKernelGGL(k_linesearch<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du, J_cur,
-                           descent, x_new, u_new, J_new, stepsize, ntrials, status);
+        hipLaunchKernelGGL(k_ls_final<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, a, p->ref, u, x0, du, x_new, u_new,
+                           J_new, stepsize, status, sc.mask0, cur);
     else
-        hipLaunchKernelGGL(k_linesearch<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du, J_cur,
-                           descent, x_new, u_new, J_new, stepsize, ntrials, status);
-    return check_launch("k_linesearch");
+        hipLaunchKernelGGL(k_ls_final<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, a, p->ref, u, x0, du, x_new, u_new,
+                           J_new, stepsize, status, sc.mask0, cur);
+    return check_launch("aoc_linesearch");
 }
 
 size_t aoc_workspace_bytes(int32_t B, int32_t T) {
-    // K~ (14) + g (2) + du (2) components, tiled
-    return aoc_tiled_elems(B, T, 18) * sizeof(double);
+    // K~ (14) + g (2) + du (2) components, tiled; then the line-search scratch
+    return aoc_tiled_elems(B, T, 18) * sizeof(double) + aoc_linesearch_scratch_bytes(B);
 }
 
 int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, const double* x, const double* u,
@@ -665,7 +843,8 @@ int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, 
     if (rc) return rc;
     rc = aoc_forward(p, prm->stepsize_0, x, u, x0, Kt, g, du, descent, x_new, u_new, J_new, status);
     if (rc) return rc;
-    return aoc_linesearch(p, prm, u, x0, du, J_cur, descent, x_new, u_new, J_new, stepsize, ntrials, status);
+    void* scratch = (void*)(du + aoc_tiled_elems(p->B, p->T, 2));
+    return aoc_linesearch(p, prm, u, x0, du, J_cur, descent, x_new, u_new, J_new, stepsize, ntrials, status, scratch);
 }
 
 }  // extern "C"

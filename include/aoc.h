@@ -158,10 +158,15 @@ int aoc_forward(const aoc_problem *prob, double alpha0, const double *x, const d
  * is accepted and (x_new,u_new,J_new) are left as written by aoc_forward.  Otherwise trials
  * ii = 1 .. armijo_maxiters-1 are rolled out (cost only) until accepted; on exhaustion the untested
  * step stepsize_0*beta^armijo_maxiters is used (Q5); then the accepted step is rolled out into
- * x_new/u_new and J_new is its cost.  stepsize[b], ntrials[b] report the result. */
+ * x_new/u_new and J_new is its cost.  stepsize[b], ntrials[b] report the result.
+ * scratch: device memory of aoc_linesearch_scratch_bytes(B) bytes -> compacted back-tracking (one
+ * launch per trial round over the still-searching trajectories only); NULL -> a single lock-step
+ * launch (every wavefront runs as many rounds as its slowest lane).  Same results either way. */
+size_t aoc_linesearch_scratch_bytes(int32_t B);
 int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, const double *u, const double *x0,
                    const double *du, const double *J_cur, const double *descent, double *x_new,
-                   double *u_new, double *J_new, double *stepsize, int32_t *ntrials, int32_t *status);
+                   double *u_new, double *J_new, double *stepsize, int32_t *ntrials, int32_t *status,
+                   void *scratch);
 
 /* ---------------------------------------------------------------------------------------------
  * Iteration level.  Workspace: caller-allocated device memory of aoc_workspace_bytes(B,T) bytes.

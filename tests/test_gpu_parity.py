@@ -302,3 +302,49 @@ def test_initial_trajectory_on_device(aoc):
         xo, uo = orc.initial_trajectory(mdl, xr)
         assert np.array_equal(xx[b], xo) and np.array_equal(uu[b], uo)
         assert rel_err(xx[b], m["xx_init"][b], 1e-2) < 2e-4
+
+
+def test_linesearch_compacted_equals_lockstep_and_oracle(aoc):
+    """A1: the compacted back-tracking (one launch per trial round over the still-searching
+    trajectories) gives bit-identical results to the single lock-step launch, and the accepted steps /
+    trial counts of both equal the oracle's armijo_stepsize on the same (u, du)."""
+    from aircraftoptimalcontrol_amd import problems
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    op = orc.OracleProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 1000
+    x0 = problems.random_x0(B, seed=99)
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    res = []
+    for compact in (True, False):
+        s = aoc.NewtonBatchSolver(bp, B, prm)
+        s.compact_linesearch = compact
+        s.set_initial_from_x0(x0)
+        h = []
+        for kk in range(4):
+            s.iterate_timed(kk)
+            h.append(s.scalars())
+        res.append((h, s.current()))
+    (h1, (x1, u1)), (h2, (x2, u2)) = res
+    assert np.array_equal(x1, x2) and np.array_equal(u1, u2)
+    for a, b in zip(h1, h2):
+        for key in ("stepsize", "ntrials", "cost_new", "descent", "status"):
+            assert np.array_equal(a[key], b[key]), key
+    assert max(h["ntrials"].max() for h in h1) >= 4  # the case exercises several trial rounds
+    # iterate() (one C call) takes the compacted route as well
+    s = aoc.NewtonBatchSolver(bp, B, prm)
+    s.set_initial_from_x0(x0)
+    for kk in range(4):
+        s.iterate(kk)
+    x3, u3 = s.current()
+    assert np.array_equal(x1, x3) and np.array_equal(u1, u3)
+    # oracle on a sample of trajectories, first iteration
+    s = aoc.NewtonBatchSolver(bp, B, prm)
+    s.set_initial_from_x0(x0)
+    xi, ui = s.current()
+    s.iterate(0)
+    sc = s.scalars()
+    oprm = orc.params()
+    for b in range(0, B, 37):
+        r = orc.newton_iterate(op, oprm, 0, xi[b], ui[b], xi[b][:, 0])
+        assert r["stepsize"] == sc["stepsize"][b] and r["ntrials"] == sc["ntrials"][b], b
