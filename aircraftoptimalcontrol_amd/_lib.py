@@ -73,7 +73,7 @@ SYMBOLS = {
     "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
     "aoc_forward": (C.c_int, [_P, _D] + [_P] * 11),
     "aoc_linesearch_scratch_bytes": (_Z, [_I]),
-    "aoc_linesearch": (C.c_int, [_P] * 14),
+    "aoc_linesearch": (C.c_int, [_P] * 15),
     "aoc_workspace_bytes": (_Z, [_I, _I]),
     "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 12),
 }

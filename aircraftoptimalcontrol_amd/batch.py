@@ -186,7 +186,6 @@ class NewtonBatchSolver:
         self.ntrials = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         self.status = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         self.x0 = torch.zeros((self.nt, 6, TILE), dtype=torch.float64, device=dev)
-        self.compact_linesearch = True   # False: lock-step variant in iterate_timed (A/B measurements)
         self.cur = 0      # index of the buffer holding the current iterate
         self.kk = 0       # outer-iteration index of the current iterate
         self.jcur = 0
@@ -258,14 +257,13 @@ class NewtonBatchSolver:
                                  _ptr(Kt), _ptr(g), None, _ptr(self.status)), "aoc_backward")
         ev[1].record(st)
         check(lib().aoc_forward(C.byref(p), prm.stepsize_0, _ptr(self.xb[c]), _ptr(self.ub[c]), _ptr(self.x0),
-                                _ptr(Kt), _ptr(g), _ptr(du), _ptr(self.descent), _ptr(self.xb[n]), _ptr(self.ub[n]),
+                                _ptr(Kt), _ptr(g), _ptr(du), _ptr(self.descent), None, None,
                                 _ptr(self.J[jn]), _ptr(self.status)), "aoc_forward")
         ev[2].record(st)
         check(lib().aoc_linesearch(C.byref(p), C.byref(prm), _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
-                                   _ptr(self.J[jc]), _ptr(self.descent), _ptr(self.xb[n]), _ptr(self.ub[n]),
-                                   _ptr(self.J[jn]), _ptr(self.stepsize), _ptr(self.ntrials), _ptr(self.status),
-                                   _ptr(self.ws[nel14 + 2 * nel2:]) if self.compact_linesearch else None),
-              "aoc_linesearch")
+                                   _ptr(self.J[jc]), _ptr(self.descent), _ptr(self.J[jn]), _ptr(self.xb[n]),
+                                   _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.stepsize), _ptr(self.ntrials),
+                                   _ptr(self.status), _ptr(self.ws[nel14 + 2 * nel2:])), "aoc_linesearch")
         ev[3].record(st)
         self.cur, self.jcur, self.kk = n, jn, kk + 1
         return ev

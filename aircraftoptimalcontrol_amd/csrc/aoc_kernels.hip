@@ -308,7 +308,7 @@ __global__ __launch_bounds__(TILE) void k_backward(KConst k, const double* __res
 }
 
 // Forward pass (see aoc_forward in include/aoc.h).
-template <bool DIAG>
+template <bool DIAG, bool WRITE>
 __global__ __launch_bounds__(TILE) void k_forward(KConst k, double alpha0, const double* __restrict__ ref,
                                                   const double* __restrict__ x, const double* __restrict__ u,
                                                   const double* __restrict__ x0, const double* __restrict__ Kt,
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(TILE) void k_forward(KConst k, double alpha0, const
     for (int c = 0; c < 6; c++) {
         dx[c] = 0.0;  // ltv_LQR is called with x0 = 0 (optcon.py:470)
         xp[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
-        x_new[tix<6>(tile, T, 0, c, lane)] = xp[c];
+        if (WRITE) x_new[tix<6>(tile, T, 0, c, lane)] = xp[c];
     }
     double desc = 0.0, JJ = 0.0;
     // software prefetch of stage t+1 operands
@@ -379,16 +379,22 @@ __global__ __launch_bounds__(TILE) void k_forward(KConst k, double alpha0, const
         if (!(xp[2] > 0.0)) flags |= AOC_ST_VNONPOS;
         const SC s2 = trig(xp[3], xp[5]);
         step_state(k, xp, u0, u1, s2, xpn);
-        u_new[tix<2>(tile, T, t, 0, lane)] = u0;
-        u_new[tix<2>(tile, T, t, 1, lane)] = u1;
+        if (WRITE) {
+            u_new[tix<2>(tile, T, t, 0, lane)] = u0;
+            u_new[tix<2>(tile, T, t, 1, lane)] = u1;
 #pragma unroll
-        for (int c = 0; c < 6; c++) { x_new[tix<6>(tile, T, t + 1, c, lane)] = xpn[c]; xp[c] = xpn[c]; }
+            for (int c = 0; c < 6; c++) x_new[tix<6>(tile, T, t + 1, c, lane)] = xpn[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) xp[c] = xpn[c];
     }
     JJ += term_cost<DIAG>(k, xp, ref + (size_t)(T - 1) * 8, q);
     du_out[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
     du_out[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
-    u_new[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
-    u_new[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
+    if (WRITE) {
+        u_new[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
+        u_new[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
+    }
     if (JJ != JJ || JJ - JJ != 0.0 || desc != desc || desc - desc != 0.0) flags |= AOC_ST_NAN;
     descent[b] = desc;
     J_new[b] = JJ;
@@ -401,103 +407,106 @@ __device__ __forceinline__ bool armijo_reject(double Jt, double JP, double cc, d
 }
 #pragma clang fp contract(fast)
 
-// Armijo back-tracking after the first trial + final update (see aoc_linesearch in include/aoc.h).
-template <bool DIAG>
-__global__ __launch_bounds__(TILE) void k_linesearch(KConst k, aoc_params prm, const double* __restrict__ ref,
-                                                     const double* __restrict__ u, const double* __restrict__ x0,
-                                                     const double* __restrict__ du, const double* __restrict__ J_cur,
-                                                     const double* __restrict__ descent, double* __restrict__ x_new,
-                                                     double* __restrict__ u_new, double* __restrict__ J_new,
-                                                     double* __restrict__ stepsize, int* __restrict__ ntrials,
-                                                     int* __restrict__ status) {
-    const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane;
-    const double JP = J_cur[b], d = descent[b];
-    double a = prm.stepsize_0;
-    int ntr = 1, flags = 0;
-    bool done = !armijo_reject(J_new[b], JP, prm.cc, a, d);
-    const bool first_ok = done;
-    if (__all(done)) {  // whole wavefront accepted the first trial: nothing to do
-        stepsize[b] = a;
-        ntrials[b] = 1;
-        return;
-    }
-    if (!done) a = prm.beta * a;  // optcon.py:270
-    double xs[6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
-    for (int ii = 1; ii < prm.armijo_maxiters; ii++) {
-        if (__all(done)) break;
-        int f2 = 0;
-        const double Jt = rollout<DIAG, false>(k, ref, tile, lane, xs, u, du, a, false, nullptr, nullptr, f2);
-        if (!done) {
-            ntr++;
-            if (armijo_reject(Jt, JP, prm.cc, a, d)) a = prm.beta * a;
-            else done = true;
-        }
-    }
-    if (!done) flags |= AOC_ST_ARMIJO_EXH;  // `a` is now the never-evaluated stepsize_0*beta^maxiters (Q5)
-    // final update (optcon.py:488-491) for the lanes whose first trial was rejected
-    const double Jf = rollout<DIAG, true>(k, ref, tile, lane, xs, u, du, a, !first_ok, x_new, u_new, flags);
-    if (!first_ok) {
-        if (Jf != Jf || Jf - Jf != 0.0) flags |= AOC_ST_NAN;
-        J_new[b] = Jf;
-        stepsize[b] = a;
-        ntrials[b] = ntr;
-        if (status && flags) status[b] |= flags;
-    } else {
-        stepsize[b] = prm.stepsize_0;
-        ntrials[b] = 1;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Compacted Armijo back-tracking.
+// Armijo back-tracking (optcon.py:243-273) + final update (optcon.py:488-491), batched.
 //
-// Lock-step back-tracking inside a tile costs max-over-64-lanes trials per wavefront while the mean
-// is ~1.2-2.  Instead the rejected trajectories are compacted, in tile order, over as few
-// wavefronts as possible, one launch per trial round r (all trajectories share the step
-// a_r = stepsize_0*beta^r, optcon.py:240/:270).  A compacted lane gathers its (u, du) elements from
-// its home tile; because the work list is in tile order a wavefront covers a few neighbouring tiles
-// and touches about the same cache lines a coalesced pass over them would.
-//   k_ls_init   : trial-0 verdicts -> bit mask per tile (bit l = lane l still searching)
-//   k_ls_scan   : exclusive prefix sum of popcounts over tiles (one workgroup), mask copy for the round
-//   k_ls_trial  : compacted cost-only rollouts of round r; accepted lanes clear their bit
-//   k_ls_final  : exhausted lanes get the untested step (Q5); every lane rejected at trial 0 is rolled
-//                 out with its accepted step into x_new/u_new (coalesced, masked; optcon.py:488-491)
+// A rollout is a strictly serial chain over T stages and a wavefront issues in order, so one trial
+// costs ~T * (a few hundred instructions) of wall time however few trajectories still search, and
+// back-tracking inside a tile would cost max-over-64-lanes trials per wavefront (mean trials are
+// 1.2-2.2, the max over a tile is 5-8).  So the search runs in rounds over the still-searching
+// trajectories only, compacted in tile order over as few wavefronts as possible, and when those are
+// fewer than the chip has SIMDs the round evaluates the next K candidate steps of every trajectory
+// at once, each (trajectory, step) pair on its own lane: the reference tries steps one by one, the
+// first accepted index is the same.
+//   k_ls_init  : trial-0 verdicts (J' of aoc_forward) -> bit mask per tile; step table a_r = s0*beta^r
+//   k_ls_plan  : (one workgroup) resolve the previous round, prefix-sum the masks, choose K
+//   k_ls_trial : cost-only rollouts of (trajectory, a_{r+k}); accept -> atomicMin(first_ok[b], r+k)
+//   k_ls_final : resolve the last round; exhausted searches take the never-evaluated
+//                s0*beta^maxiters (Q5); every trajectory is rolled out with its step into x_new/u_new
+//                (full-tile coalesced stores) and J_new
+// A compacted lane gathers its (u, du) elements from its home tile; the work list is in tile order,
+// so a wavefront touches about the cache lines a coalesced pass over the same tiles would.
 // ---------------------------------------------------------------------------------------------
+constexpr int LS_MAX_STEPS = 64;   // armijo_maxiters <= 63
+constexpr int LS_NOT_FOUND = 0x7fffffff;
+
+struct LsState {
+    int r_next;   // first step index not yet evaluated
+    int r_start;  // this round evaluates indices r_start .. r_start+K-1
+    int K;
+    int count;    // trajectories searching in this round
+    int nw;       // wavefronts per step index = ceil(count/64)
+    int pad[3];
+    double alpha[LS_MAX_STEPS];
+};
+
 struct LsScratch {
-    unsigned long long* mask0;  // [ntiles] rejected at trial 0
-    unsigned long long* maskA;  // [ntiles] ping
-    unsigned long long* maskB;  // [ntiles] pong
-    int* prefix;                // [ntiles+1]
+    unsigned long long* mask;  // [ntiles]  bit l: lane l still searching
+    int* prefix;               // [ntiles+1]
+    int* first_ok;             // [ntiles*64]
+    LsState* st;
 };
 
 __global__ __launch_bounds__(TILE) void k_ls_init(aoc_params prm, const double* __restrict__ J_cur,
                                                   const double* __restrict__ descent,
-                                                  const double* __restrict__ J_new, double* __restrict__ stepsize,
+                                                  const double* __restrict__ J_trial0, double* __restrict__ stepsize,
                                                   int* __restrict__ ntrials, LsScratch sc) {
     const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane;
-    const bool rej = armijo_reject(J_new[b], J_cur[b], prm.cc, prm.stepsize_0, descent[b]);
+    const bool rej = armijo_reject(J_trial0[b], J_cur[b], prm.cc, prm.stepsize_0, descent[b]);
     const unsigned long long m = __ballot(rej);
     stepsize[b] = prm.stepsize_0;
     ntrials[b] = 1;
-    if (lane == 0) { sc.mask0[tile] = m; sc.maskA[tile] = m; }
+    sc.first_ok[b] = LS_NOT_FOUND;
+    if (lane == 0) sc.mask[tile] = m;
+    if (tile == 0 && lane == 0) {
+        double a = prm.stepsize_0;
+        sc.st->alpha[0] = a;
+        for (int i = 1; i <= prm.armijo_maxiters; i++) { a = prm.beta * a; sc.st->alpha[i] = a; }  // optcon.py:270
+        sc.st->r_next = 1;
+        sc.st->r_start = 1;
+        sc.st->K = 0;
+        sc.st->count = 0;
+        sc.st->nw = 0;
+    }
 }
 
-// one workgroup of 1024 threads; in -> prefix (exclusive, prefix[ntiles] = total), out = copy of in
-__global__ __launch_bounds__(1024) void k_ls_scan(int ntiles, const unsigned long long* __restrict__ in,
-                                                  unsigned long long* __restrict__ out, int* __restrict__ prefix) {
+// resolve one tile's searching lanes against first_ok; returns the updated mask (lane-parallel)
+__device__ __forceinline__ unsigned long long ls_resolve(unsigned long long m, int b, int r_done,
+                                                         const LsState* st, int* __restrict__ first_ok,
+                                                         double* __restrict__ stepsize, int* __restrict__ ntrials,
+                                                         int lane) {
+    const bool searching = (m >> lane) & 1ull;
+    bool still = false;
+    if (searching) {
+        const int f = first_ok[b];
+        if (f != LS_NOT_FOUND) { stepsize[b] = st->alpha[f]; ntrials[b] = f + 1; }
+        else { ntrials[b] = r_done; still = true; }
+    }
+    return __ballot(still);
+}
+
+// One workgroup (16 wavefronts): wavefront w resolves tiles w, w+16, ...; then prefix sums and the plan.
+__global__ __launch_bounds__(1024) void k_ls_plan(int ntiles, int maxiters, int wcap, LsScratch sc,
+                                                  double* __restrict__ stepsize, int* __restrict__ ntrials) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    LsState* st = sc.st;
+    const int r_done = st->r_next;  // indices < r_next have been evaluated for every searching lane
+    if (st->K > 0) {
+        for (int tile = wv; tile < ntiles; tile += 16) {
+            const unsigned long long m = sc.mask[tile];
+            if (m == 0ull) continue;
+            const unsigned long long m2 = ls_resolve(m, tile * TILE + lane, r_done, st, sc.first_ok, stepsize, ntrials, lane);
+            if (lane == 0) sc.mask[tile] = m2;
+        }
+    }
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < ntiles; base += 1024) {
         const int i = base + tid;
-        unsigned long long m = 0;
-        if (i < ntiles) { m = in[i]; out[i] = m; }
-        const int c = __popcll(m);
-        int incl = c;  // inclusive scan inside the wavefront
+        const int c = (i < ntiles) ? __popcll(sc.mask[i]) : 0;
+        int incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int v = __shfl_up(incl, off);
@@ -508,12 +517,27 @@ __global__ __launch_bounds__(1024) void k_ls_scan(int ntiles, const unsigned lon
         int woff = 0;
         for (int w = 0; w < wv; w++) woff += wsum[w];
         const int carry = carry_s;
-        if (i < ntiles) prefix[i] = carry + woff + incl - c;
+        if (i < ntiles) sc.prefix[i] = carry + woff + incl - c;
         __syncthreads();
         if (tid == 1023) carry_s = carry + woff + incl;
         __syncthreads();
     }
-    if (tid == 0) prefix[ntiles] = carry_s;
+    if (tid == 0) {
+        const int count = carry_s;
+        sc.prefix[ntiles] = count;
+        const int nw = (count + TILE - 1) / TILE;
+        int K = 0;
+        if (count > 0 && r_done < maxiters) {
+            K = wcap / nw;
+            if (K < 1) K = 1;
+            if (K > maxiters - r_done) K = maxiters - r_done;
+        }
+        st->r_start = r_done;
+        st->K = K;
+        st->count = count;
+        st->nw = nw;
+        st->r_next = r_done + K;
+    }
 }
 
 __device__ __forceinline__ int nth_set_bit(unsigned long long m, int rank) {
@@ -529,69 +553,66 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int rank) {
 }
 
 template <bool DIAG>
-__global__ __launch_bounds__(TILE) void k_ls_trial(KConst k, aoc_params prm, double a_r, int round,
-                                                   const double* __restrict__ ref, const double* __restrict__ u,
-                                                   const double* __restrict__ x0, const double* __restrict__ du,
-                                                   const double* __restrict__ J_cur, const double* __restrict__ descent,
-                                                   double* __restrict__ stepsize, int* __restrict__ ntrials,
-                                                   const unsigned long long* __restrict__ mask_in,
-                                                   unsigned long long* __restrict__ mask_out,
-                                                   const int* __restrict__ prefix) {
-    const int count = prefix[k.ntiles];
-    const int first = blockIdx.x * TILE;
-    if (first >= count) return;
+__global__ __launch_bounds__(TILE) void k_ls_trial(KConst k, aoc_params prm, const double* __restrict__ ref,
+                                                   const double* __restrict__ u, const double* __restrict__ x0,
+                                                   const double* __restrict__ du, const double* __restrict__ J_cur,
+                                                   const double* __restrict__ descent, LsScratch sc) {
+    const LsState* st = sc.st;
+    const int K = st->K, nw = st->nw;
+    const int w = blockIdx.x;
+    if (w >= K * nw) return;
+    const int kidx = w / nw, slot = w - kidx * nw;
+    const int r = st->r_start + kidx;
+    const double a_r = st->alpha[r];
+    const int count = st->count;
     const int lane = threadIdx.x;
+    const int first = slot * TILE;
     const bool valid = first + lane < count;
     const int j = valid ? first + lane : count - 1;  // idle lanes shadow the last item (loads stay in range)
-    // tile with prefix[tile] <= j < prefix[tile+1]
-    int lo = 0, hi = k.ntiles;
+    const int* __restrict__ prefix = sc.prefix;
+    int lo = 0, hi = k.ntiles;  // tile with prefix[tile] <= j < prefix[tile+1]
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (prefix[mid] <= j) lo = mid; else hi = mid;
     }
     const int tile = lo;
-    const int hl = nth_set_bit(mask_in[tile], j - prefix[tile]);  // home lane inside the tile
+    const int hl = nth_set_bit(sc.mask[tile], j - prefix[tile]);  // home lane inside the tile
     const int b = tile * TILE + hl;
     double xs[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) xs[c] = x0[((size_t)tile * 6 + c) * TILE + hl];
     int f2 = 0;
     const double Jt = rollout<DIAG, false>(k, ref, tile, hl, xs, u, du, a_r, false, nullptr, nullptr, f2);
-    if (valid) {
-        ntrials[b] = round + 1;
-        if (!armijo_reject(Jt, J_cur[b], prm.cc, a_r, descent[b])) {
-            stepsize[b] = a_r;
-            atomicAnd(&mask_out[tile], ~(1ull << hl));
-        }
-    }
+    if (valid && !armijo_reject(Jt, J_cur[b], prm.cc, a_r, descent[b])) atomicMin(&sc.first_ok[b], r);
 }
 
 template <bool DIAG>
-__global__ __launch_bounds__(TILE) void k_ls_final(KConst k, double a_exhausted, const double* __restrict__ ref,
+__global__ __launch_bounds__(TILE) void k_ls_final(KConst k, int maxiters, const double* __restrict__ ref,
                                                    const double* __restrict__ u, const double* __restrict__ x0,
                                                    const double* __restrict__ du, double* __restrict__ x_new,
                                                    double* __restrict__ u_new, double* __restrict__ J_new,
-                                                   double* __restrict__ stepsize, int* __restrict__ status,
-                                                   const unsigned long long* __restrict__ mask0,
-                                                   const unsigned long long* __restrict__ mask_left) {
+                                                   double* __restrict__ stepsize, int* __restrict__ ntrials,
+                                                   int* __restrict__ status, LsScratch sc) {
     const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane;
-    const unsigned long long m0 = mask0[tile];
-    if (m0 == 0ull) return;  // the whole tile accepted the first trial
-    const bool mine = (m0 >> lane) & 1ull;
-    const bool exhausted = (mask_left[tile] >> lane) & 1ull;
+    const LsState* st = sc.st;
     int flags = 0;
-    double a = stepsize[b];
-    if (exhausted) { a = a_exhausted; flags |= AOC_ST_ARMIJO_EXH; }  // never evaluated (Q5)
+    const unsigned long long m = sc.mask[tile];
+    if (m != 0ull) {  // resolve the last round; what is still searching has exhausted the line search
+        const unsigned long long left = (st->K > 0) ? ls_resolve(m, b, st->r_next, st, sc.first_ok, stepsize, ntrials, lane) : m;
+        if ((left >> lane) & 1ull) {
+            stepsize[b] = st->alpha[maxiters];  // never evaluated (Q5, optcon.py:327)
+            ntrials[b] = maxiters;
+            flags |= AOC_ST_ARMIJO_EXH;
+        }
+    }
+    const double a = stepsize[b];
     double xs[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
-    const double Jf = rollout<DIAG, true>(k, ref, tile, lane, xs, u, du, a, mine, x_new, u_new, flags);
-    if (mine) {
-        if (Jf != Jf || Jf - Jf != 0.0) flags |= AOC_ST_NAN;
-        J_new[b] = Jf;
-        stepsize[b] = a;
-        if (status && flags) status[b] |= flags;
-    }
+    const double Jf = rollout<DIAG, true>(k, ref, tile, lane, xs, u, du, a, true, x_new, u_new, flags);
+    if (Jf != Jf || Jf - Jf != 0.0) flags |= AOC_ST_NAN;
+    J_new[b] = Jf;
+    if (status && flags) status[b] |= flags;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -760,68 +781,65 @@ int aoc_forward(const aoc_problem* p, double alpha0, const double* x, const doub
                 double* J_new, int32_t* status) {
     int rc = check_problem(p);
     if (rc) return rc;
-    if (!x || !u || !x0 || !Kt || !g || !du || !descent || !x_new || !u_new || !J_new) return AOC_EINVAL;
+    if (!x || !u || !x0 || !Kt || !g || !du || !descent || !J_new) return AOC_EINVAL;
+    if ((x_new == nullptr) != (u_new == nullptr)) return AOC_EINVAL;
     KConst k = make_const(p);
     hipStream_t st = (hipStream_t)p->stream;
-    if (k.diag)
-        hipLaunchKernelGGL(k_forward<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, alpha0, p->ref, x, u, x0, Kt, g, du,
-                           descent, x_new, u_new, J_new, status);
-    else
-        hipLaunchKernelGGL(k_forward<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, alpha0, p->ref, x, u, x0, Kt, g,
-                           du, descent, x_new, u_new, J_new, status);
+    const bool w = x_new != nullptr;
+#define LAUNCH_FW(D, W)                                                                                          \
+    hipLaunchKernelGGL((k_forward<D, W>), dim3(k.ntiles), dim3(TILE), 0, st, k, alpha0, p->ref, x, u, x0, Kt, g, du, \
+                       descent, x_new, u_new, J_new, status)
+    if (k.diag) { if (w) LAUNCH_FW(true, true); else LAUNCH_FW(true, false); }
+    else { if (w) LAUNCH_FW(false, true); else LAUNCH_FW(false, false); }
+#undef LAUNCH_FW
     return check_launch("k_forward");
 }
 
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
 size_t aoc_linesearch_scratch_bytes(int32_t B) {
     const size_t nt = (size_t)aoc_ntiles(B);
-    return 3 * nt * sizeof(unsigned long long) + ((nt + 1 + 1) & ~(size_t)1) * sizeof(int);
+    return align_up(nt * sizeof(unsigned long long), 16) + align_up((nt + 1) * sizeof(int), 16) +
+           align_up(nt * TILE * sizeof(int), 16) + align_up(sizeof(LsState), 16);
 }
 
 int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, const double* u, const double* x0, const double* du,
-                   const double* J_cur, const double* descent, double* x_new, double* u_new, double* J_new,
-                   double* stepsize, int32_t* ntrials, int32_t* status, void* scratch) {
+                   const double* J_cur, const double* descent, const double* J_trial0, double* x_new, double* u_new,
+                   double* J_new, double* stepsize, int32_t* ntrials, int32_t* status, void* scratch) {
     int rc = check_problem(p);
     if (rc) return rc;
-    if (!prm || !u || !x0 || !du || !J_cur || !descent || !x_new || !u_new || !J_new || !stepsize || !ntrials)
+    if (!prm || !u || !x0 || !du || !J_cur || !descent || !J_trial0 || !x_new || !u_new || !J_new || !stepsize ||
+        !ntrials || !scratch)
         return AOC_EINVAL;
-    if (prm->armijo_maxiters < 1) return AOC_EINVAL;
+    if (prm->armijo_maxiters < 1 || prm->armijo_maxiters >= LS_MAX_STEPS) return AOC_EINVAL;
     KConst k = make_const(p);
     hipStream_t st = (hipStream_t)p->stream;
-    if (!scratch) {  // lock-step variant: one launch, back-tracking inside each tile
-        if (k.diag)
-            hipLaunchKernelGGL(k_linesearch<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du,
-                               J_cur, descent, x_new, u_new, J_new, stepsize, ntrials, status);
-        else
-            hipLaunchKernelGGL(k_linesearch<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du,
-                               J_cur, descent, x_new, u_new, J_new, stepsize, ntrials, status);
-        return check_launch("k_linesearch");
-    }
+    const size_t nt = (size_t)k.ntiles;
     LsScratch sc;
-    sc.mask0 = (unsigned long long*)scratch;
-    sc.maskA = sc.mask0 + k.ntiles;
-    sc.maskB = sc.maskA + k.ntiles;
-    sc.prefix = (int*)(sc.maskB + k.ntiles);
-    hipLaunchKernelGGL(k_ls_init, dim3(k.ntiles), dim3(TILE), 0, st, *prm, J_cur, descent, J_new, stepsize, ntrials, sc);
-    unsigned long long *cur = sc.maskA, *nxt = sc.maskB;
-    double a = prm->stepsize_0;
+    char* base = (char*)scratch;
+    sc.mask = (unsigned long long*)base;  base += align_up(nt * sizeof(unsigned long long), 16);
+    sc.prefix = (int*)base;               base += align_up((nt + 1) * sizeof(int), 16);
+    sc.first_ok = (int*)base;             base += align_up(nt * TILE * sizeof(int), 16);
+    sc.st = (LsState*)base;
+    // wavefronts a trial round may occupy: about 1.5 per SIMD (256 CUs x 4 SIMDs), at least one per tile
+    const int wcap = k.ntiles > 1536 ? k.ntiles : 1536;
+    hipLaunchKernelGGL(k_ls_init, dim3(k.ntiles), dim3(TILE), 0, st, *prm, J_cur, descent, J_trial0, stepsize, ntrials, sc);
     for (int r = 1; r < prm->armijo_maxiters; r++) {
-        a = prm->beta * a;  // optcon.py:270
-        hipLaunchKernelGGL(k_ls_scan, dim3(1), dim3(1024), 0, st, k.ntiles, cur, nxt, sc.prefix);
+        hipLaunchKernelGGL(k_ls_plan, dim3(1), dim3(1024), 0, st, k.ntiles, prm->armijo_maxiters, wcap, sc, stepsize,
+                           ntrials);
         if (k.diag)
-            hipLaunchKernelGGL(k_ls_trial<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, a, r, p->ref, u, x0, du,
-                               J_cur, descent, stepsize, ntrials, cur, nxt, sc.prefix);
+            hipLaunchKernelGGL(k_ls_trial<true>, dim3(wcap), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du, J_cur,
+                               descent, sc);
         else
-            hipLaunchKernelGGL(k_ls_trial<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, a, r, p->ref, u, x0, du,
-                               J_cur, descent, stepsize, ntrials, cur, nxt, sc.prefix);
-        unsigned long long* t = cur; cur = nxt; nxt = t;
+            hipLaunchKernelGGL(k_ls_trial<false>, dim3(wcap), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du, J_cur,
+                               descent, sc);
     }
-    a = prm->beta * a;  // the step an exhausted search returns without evaluating it (optcon.py:327)
     if (k.diag)
-        hipLaunchKernelGGL(k_ls_final<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, a, p->ref, u, x0, du, x_new, u_new,
-                           J_new, stepsize, status, sc.mask0, cur);
+        hipLaunchKernelGGL(k_ls_final<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, prm->armijo_maxiters, p->ref, u, x0,
+                           du, x_new, u_new, J_new, stepsize, ntrials, status, sc);
     else
-        hipLaunchKernelGGL(k_ls_final<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, a, p->ref, u, x0, du, x_new, u_new,
-                           J_new, stepsize, status, sc.mask0, cur);
+        hipLaunchKernelGGL(k_ls_final<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, prm->armijo_maxiters, p->ref, u, x0,
+                           du, x_new, u_new, J_new, stepsize, ntrials, status, sc);
     return check_launch("aoc_linesearch");
 }
 
@@ -841,10 +859,12 @@ int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, 
     double* du = g + aoc_tiled_elems(p->B, p->T, 2);
     rc = aoc_backward(p, kk > prm->hessian_switch, x, u, Kt, g, nullptr, status);
     if (rc) return rc;
-    rc = aoc_forward(p, prm->stepsize_0, x, u, x0, Kt, g, du, descent, x_new, u_new, J_new, status);
+    // J_new doubles as the holder of the first trial's cost J'(stepsize_0) until the line search overwrites it
+    rc = aoc_forward(p, prm->stepsize_0, x, u, x0, Kt, g, du, descent, nullptr, nullptr, J_new, status);
     if (rc) return rc;
     void* scratch = (void*)(du + aoc_tiled_elems(p->B, p->T, 2));
-    return aoc_linesearch(p, prm, u, x0, du, J_cur, descent, x_new, u_new, J_new, stepsize, ntrials, status, scratch);
+    return aoc_linesearch(p, prm, u, x0, du, J_cur, descent, J_new, x_new, u_new, J_new, stepsize, ntrials, status,
+                          scratch);
 }
 
 }  // extern "C"

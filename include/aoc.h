@@ -148,25 +148,26 @@ int aoc_backward(const aoc_problem *prob, int32_t full_hessian, const double *x,
 /* Forward pass: closed-loop linear rollout of ltv_LQR (optcon.py:756-762) giving du, the descent
  * sum (optcon.py:474-477), fused with the first Armijo trial (step alpha0 = stepsize_0): u' = u +
  * alpha0*du, nonlinear rollout x' from x0, cost J' (optcon.py:250-264).
- * Outputs: du (tiled C=2), descent[ntiles*64], x_new/u_new (tiled), J_new[ntiles*64]. */
+ * Outputs: du (tiled C=2), descent[ntiles*64], J_trial0[ntiles*64] = J'(alpha0); x_new/u_new (tiled)
+ * receive the trial trajectory when non-NULL (both or neither). */
 int aoc_forward(const aoc_problem *prob, double alpha0, const double *x, const double *u, const double *x0,
                 const double *Kt, const double *g, double *du, double *descent, double *x_new,
-                double *u_new, double *J_new, int32_t *status);
+                double *u_new, double *J_trial0, int32_t *status);
 
-/* Armijo back-tracking after the first trial (optcon.py:243-273) and the final update
- * (optcon.py:488-491).  For every trajectory: if J_new <= J_cur + cc*alpha0*descent the first trial
- * is accepted and (x_new,u_new,J_new) are left as written by aoc_forward.  Otherwise trials
- * ii = 1 .. armijo_maxiters-1 are rolled out (cost only) until accepted; on exhaustion the untested
- * step stepsize_0*beta^armijo_maxiters is used (Q5); then the accepted step is rolled out into
- * x_new/u_new and J_new is its cost.  stepsize[b], ntrials[b] report the result.
- * scratch: device memory of aoc_linesearch_scratch_bytes(B) bytes -> compacted back-tracking (one
- * launch per trial round over the still-searching trajectories only); NULL -> a single lock-step
- * launch (every wavefront runs as many rounds as its slowest lane).  Same results either way. */
+/* Armijo back-tracking (optcon.py:243-273) and the final update (optcon.py:488-491).
+ * Trial ii uses alpha_ii = stepsize_0*beta^ii and is accepted iff J'(alpha_ii) <= J_cur +
+ * cc*alpha_ii*descent; trial 0 is judged from J_trial0 (written by aoc_forward).  Rejected
+ * trajectories are compacted and searched in rounds; when few remain a round evaluates several
+ * candidate steps of each at once (the accepted index is the first one that passes, as in the
+ * reference's sequential loop).  On exhaustion the untested stepsize_0*beta^armijo_maxiters is used
+ * (Q5).  Finally EVERY trajectory is rolled out with its step into x_new/u_new and J_new (may alias
+ * J_trial0).  stepsize[b], ntrials[b] report the result.  armijo_maxiters <= 63.
+ * scratch: device memory of aoc_linesearch_scratch_bytes(B) bytes. */
 size_t aoc_linesearch_scratch_bytes(int32_t B);
 int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, const double *u, const double *x0,
-                   const double *du, const double *J_cur, const double *descent, double *x_new,
-                   double *u_new, double *J_new, double *stepsize, int32_t *ntrials, int32_t *status,
-                   void *scratch);
+                   const double *du, const double *J_cur, const double *descent, const double *J_trial0,
+                   double *x_new, double *u_new, double *J_new, double *stepsize, int32_t *ntrials,
+                   int32_t *status, void *scratch);
 
 /* ---------------------------------------------------------------------------------------------
  * Iteration level.  Workspace: caller-allocated device memory of aoc_workspace_bytes(B,T) bytes.
