@@ -131,7 +131,11 @@ __global__ __launch_bounds__(TILE) void k_traj_cost(KConst k, const double* __re
 }
 
 // One nonlinear rollout with cost for per-lane step `a` (get_update + trial cost).
-// WRITE: store x',u'.  wmask: lane writes (and reports J) only if true.
+// WRITE: store x',u'.  wmask: lane writes only if true.
+// The loop carries a strictly serial chain (x_t -> x_{t+1}), so the only way to keep HBM busy from
+// one wavefront is to run the (u, du) loads far ahead: a register ring of ROLL_PF stages.
+constexpr int ROLL_PF = 8;
+
 template <bool DIAG, bool WRITE>
 __device__ __forceinline__ double rollout(const KConst& k, const double* __restrict__ ref, int tile, int lane,
                                           const double x0[6], const double* __restrict__ u,
@@ -146,32 +150,49 @@ __device__ __forceinline__ double rollout(const KConst& k, const double* __restr
 #pragma unroll
         for (int c = 0; c < 6; c++) x_out[tix<6>(tile, T, 0, c, lane)] = xs[c];
     }
-    double un0 = u[tix<2>(tile, T, 0, 0, lane)], un1 = u[tix<2>(tile, T, 0, 1, lane)];
-    double dn0 = du ? du[tix<2>(tile, T, 0, 0, lane)] : 0.0, dn1 = du ? du[tix<2>(tile, T, 0, 1, lane)] : 0.0;
-    for (int t = 0; t < T - 1; t++) {
-        const double uc0 = un0, uc1 = un1, dc0 = dn0, dc1 = dn1;
-        if (t + 1 < T - 1) {  // prefetch next stage
-            un0 = u[tix<2>(tile, T, t + 1, 0, lane)]; un1 = u[tix<2>(tile, T, t + 1, 1, lane)];
-            if (du) { dn0 = du[tix<2>(tile, T, t + 1, 0, lane)]; dn1 = du[tix<2>(tile, T, t + 1, 1, lane)]; }
-        }
-        double u0, u1;
-        {
+    double ub[ROLL_PF][2], db[ROLL_PF][2];
+#pragma unroll
+    for (int i = 0; i < ROLL_PF; i++) {
+        const int t = i < T - 1 ? i : T - 2;
+        ub[i][0] = u[tix<2>(tile, T, t, 0, lane)];
+        ub[i][1] = u[tix<2>(tile, T, t, 1, lane)];
+        db[i][0] = du ? du[tix<2>(tile, T, t, 0, lane)] : 0.0;
+        db[i][1] = du ? du[tix<2>(tile, T, t, 1, lane)] : 0.0;
+    }
+    for (int t0 = 0; t0 < T - 1; t0 += ROLL_PF) {
+#pragma unroll
+        for (int i = 0; i < ROLL_PF; i++) {
+            const int t = t0 + i;
+            if (t >= T - 1) break;
+            const double uc0 = ub[i][0], uc1 = ub[i][1], dc0 = db[i][0], dc1 = db[i][1];
+            {   // refill this slot with stage t + ROLL_PF (clamped: the tail re-reads the last stage)
+                const int tn = t + ROLL_PF < T - 1 ? t + ROLL_PF : T - 2;
+                ub[i][0] = u[tix<2>(tile, T, tn, 0, lane)];
+                ub[i][1] = u[tix<2>(tile, T, tn, 1, lane)];
+                if (du) {
+                    db[i][0] = du[tix<2>(tile, T, tn, 0, lane)];
+                    db[i][1] = du[tix<2>(tile, T, tn, 1, lane)];
+                }
+            }
+            double u0, u1;
+            {
 #pragma clang fp contract(off)
-            u0 = uc0 + a * dc0;  // optcon.py:197 / :253
-            u1 = uc1 + a * dc1;
-        }
-        JJ += stage_cost<DIAG>(k, xs, u0, u1, ref + (size_t)t * 8, q, r);
-        if (!(xs[2] > 0.0)) flags |= AOC_ST_VNONPOS;
-        const SC s = trig(xs[3], xs[5]);
-        step_state(k, xs, u0, u1, s, xn);
-        if (WRITE && wmask) {
-            u_out[tix<2>(tile, T, t, 0, lane)] = u0;
-            u_out[tix<2>(tile, T, t, 1, lane)] = u1;
+                u0 = uc0 + a * dc0;  // optcon.py:197 / :253
+                u1 = uc1 + a * dc1;
+            }
+            JJ += stage_cost<DIAG>(k, xs, u0, u1, ref + (size_t)t * 8, q, r);
+            if (!(xs[2] > 0.0)) flags |= AOC_ST_VNONPOS;
+            const SC s = trig(xs[3], xs[5]);
+            step_state(k, xs, u0, u1, s, xn);
+            if (WRITE && wmask) {
+                u_out[tix<2>(tile, T, t, 0, lane)] = u0;
+                u_out[tix<2>(tile, T, t, 1, lane)] = u1;
 #pragma unroll
-            for (int c = 0; c < 6; c++) x_out[tix<6>(tile, T, t + 1, c, lane)] = xn[c];
-        }
+                for (int c = 0; c < 6; c++) x_out[tix<6>(tile, T, t + 1, c, lane)] = xn[c];
+            }
 #pragma unroll
-        for (int c = 0; c < 6; c++) xs[c] = xn[c];
+            for (int c = 0; c < 6; c++) xs[c] = xn[c];
+        }
     }
     JJ += term_cost<DIAG>(k, xs, ref + (size_t)(T - 1) * 8, q);
     if (WRITE && wmask) {
@@ -436,7 +457,8 @@ struct LsState {
     int K;
     int count;    // trajectories searching in this round
     int nw;       // wavefronts per step index = ceil(count/64)
-    int pad[3];
+    int round;    // rounds planned so far
+    int pad[2];
     double alpha[LS_MAX_STEPS];
 };
 
@@ -467,6 +489,7 @@ __global__ __launch_bounds__(TILE) void k_ls_init(aoc_params prm, const double* 
         sc.st->K = 0;
         sc.st->count = 0;
         sc.st->nw = 0;
+        sc.st->round = 0;
     }
 }
 
@@ -485,22 +508,27 @@ __device__ __forceinline__ unsigned long long ls_resolve(unsigned long long m, i
     return __ballot(still);
 }
 
-// One workgroup (16 wavefronts): wavefront w resolves tiles w, w+16, ...; then prefix sums and the plan.
-__global__ __launch_bounds__(1024) void k_ls_plan(int ntiles, int maxiters, int wcap, LsScratch sc,
-                                                  double* __restrict__ stepsize, int* __restrict__ ntrials) {
+// resolve the previous round tile by tile (one wavefront per tile)
+__global__ __launch_bounds__(TILE) void k_ls_resolve(LsScratch sc, double* __restrict__ stepsize,
+                                                     int* __restrict__ ntrials) {
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    const LsState* st = sc.st;
+    if (st->K <= 0) return;
+    const unsigned long long m = sc.mask[tile];
+    if (m == 0ull) return;
+    const unsigned long long m2 = ls_resolve(m, tile * TILE + lane, st->r_next, st, sc.first_ok, stepsize, ntrials, lane);
+    if (lane == 0) sc.mask[tile] = m2;
+}
+
+// One workgroup: exclusive prefix sum of the per-tile popcounts and the plan of the next round:
+// K candidate steps per searching trajectory, as many as keep the round within `wcap` wavefronts,
+// but not more than round+1 (rejection thins out geometrically: deep speculation only pays late).
+__global__ __launch_bounds__(1024) void k_ls_plan(int ntiles, int maxiters, int wcap, LsScratch sc) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     LsState* st = sc.st;
     const int r_done = st->r_next;  // indices < r_next have been evaluated for every searching lane
-    if (st->K > 0) {
-        for (int tile = wv; tile < ntiles; tile += 16) {
-            const unsigned long long m = sc.mask[tile];
-            if (m == 0ull) continue;
-            const unsigned long long m2 = ls_resolve(m, tile * TILE + lane, r_done, st, sc.first_ok, stepsize, ntrials, lane);
-            if (lane == 0) sc.mask[tile] = m2;
-        }
-    }
     if (tid == 0) carry_s = 0;
     __syncthreads();
     for (int base = 0; base < ntiles; base += 1024) {
@@ -526,12 +554,15 @@ __global__ __launch_bounds__(1024) void k_ls_plan(int ntiles, int maxiters, int 
         const int count = carry_s;
         sc.prefix[ntiles] = count;
         const int nw = (count + TILE - 1) / TILE;
+        const int round = st->round + 1;
         int K = 0;
         if (count > 0 && r_done < maxiters) {
             K = wcap / nw;
+            if (K > round + 1) K = round + 1;
             if (K < 1) K = 1;
             if (K > maxiters - r_done) K = maxiters - r_done;
         }
+        st->round = round;
         st->r_start = r_done;
         st->K = K;
         st->count = count;
@@ -821,12 +852,12 @@ int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, const double* u,
     sc.prefix = (int*)base;               base += align_up((nt + 1) * sizeof(int), 16);
     sc.first_ok = (int*)base;             base += align_up(nt * TILE * sizeof(int), 16);
     sc.st = (LsState*)base;
-    // wavefronts a trial round may occupy: about 1.5 per SIMD (256 CUs x 4 SIMDs), at least one per tile
-    const int wcap = k.ntiles > 1536 ? k.ntiles : 1536;
+    // wavefronts a trial round may occupy: one per SIMD (256 CUs x 4 SIMDs), at least one per tile
+    const int wcap = k.ntiles > 1024 ? k.ntiles : 1024;
     hipLaunchKernelGGL(k_ls_init, dim3(k.ntiles), dim3(TILE), 0, st, *prm, J_cur, descent, J_trial0, stepsize, ntrials, sc);
     for (int r = 1; r < prm->armijo_maxiters; r++) {
-        hipLaunchKernelGGL(k_ls_plan, dim3(1), dim3(1024), 0, st, k.ntiles, prm->armijo_maxiters, wcap, sc, stepsize,
-                           ntrials);
+        if (r > 1) hipLaunchKernelGGL(k_ls_resolve, dim3(k.ntiles), dim3(TILE), 0, st, sc, stepsize, ntrials);
+        hipLaunchKernelGGL(k_ls_plan, dim3(1), dim3(1024), 0, st, k.ntiles, prm->armijo_maxiters, wcap, sc);
         if (k.diag)
             hipLaunchKernelGGL(k_ls_trial<true>, dim3(wcap), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du, J_cur,
                                descent, sc);
