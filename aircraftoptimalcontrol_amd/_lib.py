@@ -74,6 +74,8 @@ SYMBOLS = {
     "aoc_forward": (C.c_int, [_P, _D] + [_P] * 11),
     "aoc_linesearch_scratch_bytes": (_Z, [_I]),
     "aoc_linesearch": (C.c_int, [_P] * 15),
+    "aoc_lqr_tracking": (C.c_int, [_P] * 8),
+    "aoc_ltv_lqr": (C.c_int, [_I, _I, _I] + [_P] * 17),
     "aoc_workspace_bytes": (_Z, [_I, _I]),
     "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 12),
 }

@@ -422,6 +422,236 @@ __global__ __launch_bounds__(TILE) void k_forward(KConst k, double alpha0, const
     if (status && flags) status[b] |= flags;
 }
 
+// ---------------------------------------------------------------------------------------------
+// LQR tracking (lqr_tracking.py:245-283): linearise about (x_opt,u_opt), non-augmented Riccati with
+// constant weights and S = 0, gains K (2x6), closed-loop nonlinear rollout.
+// ---------------------------------------------------------------------------------------------
+template <bool DIAG>
+__global__ __launch_bounds__(TILE) void k_track_gains(KConst k, const double* __restrict__ x,
+                                                      const double* __restrict__ u, double* __restrict__ Kout,
+                                                      int* __restrict__ status) {
+    const int tile = blockIdx.x, lane = threadIdx.x, T = k.T;
+    double P[21], p[6], Qb[21], xs[6], xn[6];
+    int flags = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        p[i] = 0.0;
+#pragma unroll
+        for (int j = i; j < 6; j++) { P[sidx(i, j)] = k.QT[i * 6 + j]; Qb[sidx(i, j)] = k.Q[i * 6 + j]; }  // :716
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, T - 2, c, lane)];
+    double un0 = u[tix<2>(tile, T, T - 2, 0, lane)];
+    for (int t = T - 2; t >= 0; t--) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) xs[c] = xn[c];
+        const double u0 = un0;
+        if (t > 0) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, t - 1, c, lane)];
+            un0 = u[tix<2>(tile, T, t - 1, 0, lane)];
+        }
+        const SC s = trig(xs[3], xs[5]);
+        const Lin l = linearise(k, xs, u0, s);
+        const double z6[6] = {0, 0, 0, 0, 0, 0}, z2[2] = {0, 0};
+        double Ks[14];
+        const StageFlags fl = lqr_stage(k, l, P, p, Qb, 0.0, 0.0, 0.0, z6, z2, Ks);
+        if (fl.singular) flags |= AOC_ST_SINGULAR;
+        if (fl.regularised) flags |= AOC_ST_REGULARISED;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            Kout[tix<12>(tile, T, t, j, lane)] = Ks[1 + j];
+            Kout[tix<12>(tile, T, t, 6 + j, lane)] = Ks[8 + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 12; j++) Kout[tix<12>(tile, T, T - 1, j, lane)] = 0.0;  // KK[:,:,T-1] stays 0 (:700)
+    if (status && flags) status[tile * TILE + lane] |= flags;
+}
+
+__global__ __launch_bounds__(TILE) void k_track_rollout(KConst k, const double* __restrict__ x,
+                                                        const double* __restrict__ u, const double* __restrict__ Kin,
+                                                        const double* __restrict__ x0, double* __restrict__ x_reg,
+                                                        double* __restrict__ u_reg, int* __restrict__ status) {
+    const int tile = blockIdx.x, lane = threadIdx.x, T = k.T;
+    double xs[6], xn[6];
+    int flags = 0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
+        x_reg[tix<6>(tile, T, 0, c, lane)] = xs[c];
+    }
+    for (int t = 0; t < T - 1; t++) {
+        double d[6], u0, u1;
+        {
+#pragma clang fp contract(off)
+            // uu_reg = uu_opt + KK @ (xx_reg - xx_opt)   (lqr_tracking.py:280)
+#pragma unroll
+            for (int c = 0; c < 6; c++) d[c] = xs[c] - x[tix<6>(tile, T, t, c, lane)];
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                a0 += Kin[tix<12>(tile, T, t, c, lane)] * d[c];
+                a1 += Kin[tix<12>(tile, T, t, 6 + c, lane)] * d[c];
+            }
+            u0 = u[tix<2>(tile, T, t, 0, lane)] + a0;
+            u1 = u[tix<2>(tile, T, t, 1, lane)] + a1;
+        }
+        if (!(xs[2] > 0.0)) flags |= AOC_ST_VNONPOS;
+        const SC s = trig(xs[3], xs[5]);
+        step_state(k, xs, u0, u1, s, xn);
+        u_reg[tix<2>(tile, T, t, 0, lane)] = u0;
+        u_reg[tix<2>(tile, T, t, 1, lane)] = u1;
+#pragma unroll
+        for (int c = 0; c < 6; c++) { x_reg[tix<6>(tile, T, t + 1, c, lane)] = xn[c]; xs[c] = xn[c]; }
+    }
+    u_reg[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
+    u_reg[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
+    if (status && flags) status[tile * TILE + lane] |= flags;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic ltv_LQR (optcon.py:533-771; copy lqr_tracking.py:6-242) with caller-supplied A,B,Q,R,S per
+// stage: dense N x N recursion (N = 6, or 7 for the augmented affine form), one problem per lane,
+// in the reference's order of operations (Riccati loop, gain loop with the PD test, rollout loop).
+// Not a throughput path: it backs the drop-in optcon.ltv_LQR and pins L1/L2 of SURVEY 8a.
+// Layouts are time-major per problem b: A [b][t][36], Bm [b][t][12] (6x2), Q [b][t][36], R [b][t][4],
+// S [b][t][12] (2x6), Qf [b][36], x0 [b][6], q [b][t][6], r [b][t][2], qf [b][6];
+// outputs KK [b][t][2*N], PP [b][t][N*N] (workspace, always needed), xx [b][t][6], uu [b][t][2].
+// ---------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+template <int N>
+__global__ void k_ltv_lqr(int nb, int T, const double* __restrict__ Ain, const double* __restrict__ Bin,
+                          const double* __restrict__ Qin, const double* __restrict__ Rin,
+                          const double* __restrict__ Sin, const double* __restrict__ Qfin,
+                          const double* __restrict__ x0, const double* __restrict__ qq, const double* __restrict__ rr,
+                          const double* __restrict__ qqf, double* __restrict__ KK, double* __restrict__ PP,
+                          double* __restrict__ xxo, double* __restrict__ uuo, int* __restrict__ nreg,
+                          int* __restrict__ nsing) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    constexpr bool AUG = (N == 7);
+    constexpr int O = AUG ? 1 : 0;
+    const double* A_ = Ain + (size_t)b * T * 36;
+    const double* B_ = Bin + (size_t)b * T * 12;
+    const double* Q_ = Qin + (size_t)b * T * 36;
+    const double* R_ = Rin + (size_t)b * T * 4;
+    const double* S_ = Sin + (size_t)b * T * 12;
+    double* P_ = PP + (size_t)b * T * N * N;
+    double* K_ = KK + (size_t)b * T * 2 * N;
+    int reg = 0, sing = 0;
+    auto Aa = [&](int t, int i, int j) -> double {  // augmented A~ = blkdiag(1, A)  (:684-685)
+        if (!AUG) return A_[(size_t)t * 36 + i * 6 + j];
+        if (i == 0 || j == 0) return (i == 0 && j == 0) ? 1.0 : 0.0;
+        return A_[(size_t)t * 36 + (i - 1) * 6 + (j - 1)];
+    };
+    auto Ba = [&](int t, int i, int j) -> double {  // B~ = [0; B]  (:686)
+        if (AUG && i == 0) return 0.0;
+        return B_[(size_t)t * 12 + (i - O) * 2 + j];
+    };
+    auto Qa = [&](int t, int i, int j) -> double {  // Q~ = [[0, q/2],[q/2, Q]]  (:673-675)
+        if (!AUG) return Q_[(size_t)t * 36 + i * 6 + j];
+        if (i == 0 && j == 0) return 0.0;
+        if (i == 0) return 0.5 * (qq ? qq[((size_t)b * T + t) * 6 + j - 1] : 0.0);
+        if (j == 0) return 0.5 * (qq ? qq[((size_t)b * T + t) * 6 + i - 1] : 0.0);
+        return Q_[(size_t)t * 36 + (i - 1) * 6 + (j - 1)];
+    };
+    auto Sa = [&](int t, int i, int j) -> double {  // S~ = [r/2, S]  (:679-680)
+        if (!AUG) return S_[(size_t)t * 12 + i * 6 + j];
+        if (j == 0) return 0.5 * (rr ? rr[((size_t)b * T + t) * 2 + i] : 0.0);
+        return S_[(size_t)t * 12 + i * 6 + j - 1];
+    };
+    // P_{T-1} = Q~f  (:688-690, :716)
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) {
+            double v;
+            if (!AUG) v = Qfin[(size_t)b * 36 + i * 6 + j];
+            else if (i == 0 && j == 0) v = 0.0;
+            else if (i == 0) v = 0.5 * (qqf ? qqf[(size_t)b * 6 + j - 1] : 0.0);
+            else if (j == 0) v = 0.5 * (qqf ? qqf[(size_t)b * 6 + i - 1] : 0.0);
+            else v = Qfin[(size_t)b * 36 + (i - 1) * 6 + (j - 1)];
+            P_[(size_t)(T - 1) * N * N + i * N + j] = v;
+        }
+    auto stage = [&](int t, bool gains) {
+        const double* Pn = P_ + (size_t)(t + 1) * N * N;
+        double AtP[N][N], BtP[2][N], G[2][N], M[4];
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < N; j++) {
+                double a = 0.0;
+                for (int l = 0; l < N; l++) a += Ba(t, l, i) * Pn[l * N + j];
+                BtP[i][j] = a;
+            }
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < N; j++) {
+                double a = 0.0;
+                for (int l = 0; l < N; l++) a += BtP[i][l] * Aa(t, l, j);
+                G[i][j] = a + Sa(t, i, j);
+            }
+        for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++) {
+                double a = 0.0;
+                for (int l = 0; l < N; l++) a += BtP[i][l] * Ba(t, l, j);
+                M[i * 2 + j] = R_[(size_t)t * 4 + i * 2 + j] + a;
+            }
+        if (gains) {
+            const double tr = M[0] + M[3], det0 = M[0] * M[3] - M[1] * M[2];
+            const double disc = 0.25 * (M[0] - M[3]) * (M[0] - M[3]) + M[1] * M[2];
+            const bool pd = (disc >= 0.0) ? (tr > 0.0 && det0 > 0.0) : (tr > 0.0);  // all(eigvals > 0), :745
+            if (!pd) { M[0] += 0.5; M[3] += 0.5; reg++; }
+        }
+        const double det = M[0] * M[3] - M[1] * M[2];
+        if (det == 0.0) sing++;
+        const double Mi[4] = {M[3] / det, -M[1] / det, -M[2] / det, M[0] / det};
+        if (gains) {  // K = (-inv(M)) @ G   (:751)
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < N; j++)
+                    K_[(size_t)t * 2 * N + i * N + j] = (-Mi[i * 2 + 0]) * G[0][j] + (-Mi[i * 2 + 1]) * G[1][j];
+            return;
+        }
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++) {
+                double a = 0.0;
+                for (int l = 0; l < N; l++) a += Aa(t, l, i) * Pn[l * N + j];
+                AtP[i][j] = a;
+            }
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++) {
+                double apa = 0.0;
+                for (int l = 0; l < N; l++) apa += AtP[i][l] * Aa(t, l, j);
+                const double gm0 = G[0][i] * Mi[0] + G[1][i] * Mi[2], gm1 = G[0][i] * Mi[1] + G[1][i] * Mi[3];
+                P_[(size_t)t * N * N + i * N + j] = (Qa(t, i, j) + apa) - (gm0 * G[0][j] + gm1 * G[1][j]);  // :727-728
+            }
+    };
+    for (int t = T - 2; t >= 0; t--) stage(t, false);   // Riccati (:719-728), never regularised (Q3)
+    for (int t = 0; t < T - 1; t++) stage(t, true);     // gains (:732-751)
+    for (int j = 0; j < 2 * N; j++) K_[(size_t)(T - 1) * 2 * N + j] = 0.0;
+    // closed-loop linear rollout (:756-762)
+    double xt[N], xn[N];
+    if (AUG) xt[0] = 1.0;
+    for (int i = 0; i < 6; i++) xt[O + i] = x0[(size_t)b * 6 + i];
+    for (int t = 0; t < T; t++) {
+        for (int i = 0; i < 6; i++) xxo[((size_t)b * T + t) * 6 + i] = xt[O + i];
+        if (t == T - 1) { uuo[((size_t)b * T + t) * 2] = 0.0; uuo[((size_t)b * T + t) * 2 + 1] = 0.0; break; }
+        double uu[2];
+        for (int i = 0; i < 2; i++) {
+            double a = 0.0;
+            for (int l = 0; l < N; l++) a += K_[(size_t)t * 2 * N + i * N + l] * xt[l];
+            uu[i] = a;
+            uuo[((size_t)b * T + t) * 2 + i] = a;
+        }
+        for (int i = 0; i < N; i++) {
+            double a = 0.0, c = 0.0;
+            for (int l = 0; l < N; l++) a += Aa(t, i, l) * xt[l];
+            for (int l = 0; l < 2; l++) c += Ba(t, i, l) * uu[l];
+            xn[i] = a + c;
+        }
+        for (int i = 0; i < N; i++) xt[i] = xn[i];
+    }
+    if (nreg) nreg[b] = reg;
+    if (nsing) nsing[b] = sing;
+}
+#pragma clang fp contract(fast)
+
 #pragma clang fp contract(off)
 __device__ __forceinline__ bool armijo_reject(double Jt, double JP, double cc, double a, double descent) {
     return Jt > JP + cc * a * descent;  // optcon.py:268
@@ -872,6 +1102,37 @@ int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, const double* u,
         hipLaunchKernelGGL(k_ls_final<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, prm->armijo_maxiters, p->ref, u, x0,
                            du, x_new, u_new, J_new, stepsize, ntrials, status, sc);
     return check_launch("aoc_linesearch");
+}
+
+int aoc_lqr_tracking(const aoc_problem* p, const double* x_opt, const double* u_opt, const double* x0_reg,
+                     double* Kgain, double* x_reg, double* u_reg, int32_t* status) {
+    int rc = check_problem(p);
+    if (rc) return rc;
+    if (!x_opt || !u_opt || !Kgain) return AOC_EINVAL;
+    if ((x_reg == nullptr) != (u_reg == nullptr) || (x_reg && !x0_reg)) return AOC_EINVAL;
+    KConst k = make_const(p);
+    hipStream_t st = (hipStream_t)p->stream;
+    if (k.diag) hipLaunchKernelGGL(k_track_gains<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, x_opt, u_opt, Kgain, status);
+    else hipLaunchKernelGGL(k_track_gains<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, x_opt, u_opt, Kgain, status);
+    if (x_reg)
+        hipLaunchKernelGGL(k_track_rollout, dim3(k.ntiles), dim3(TILE), 0, st, k, x_opt, u_opt, Kgain, x0_reg, x_reg,
+                           u_reg, status);
+    return check_launch("aoc_lqr_tracking");
+}
+
+int aoc_ltv_lqr(int32_t nb, int32_t T, int32_t augmented, const double* A, const double* Bm, const double* Q,
+                const double* R, const double* S, const double* Qf, const double* x0, const double* q,
+                const double* r, const double* qf, double* KK, double* PP, double* xx, double* uu, int32_t* nreg,
+                int32_t* nsing, void* stream) {
+    if (nb < 1 || T < 2 || !A || !Bm || !Q || !R || !S || !Qf || !x0 || !KK || !PP || !xx || !uu) return AOC_EINVAL;
+    if (!augmented && (q || r || qf)) return AOC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((nb + 63) / 64), blk(64);
+    if (augmented)
+        hipLaunchKernelGGL(k_ltv_lqr<7>, grid, blk, 0, st, nb, T, A, Bm, Q, R, S, Qf, x0, q, r, qf, KK, PP, xx, uu, nreg, nsing);
+    else
+        hipLaunchKernelGGL(k_ltv_lqr<6>, grid, blk, 0, st, nb, T, A, Bm, Q, R, S, Qf, x0, q, r, qf, KK, PP, xx, uu, nreg, nsing);
+    return check_launch("k_ltv_lqr");
 }
 
 size_t aoc_workspace_bytes(int32_t B, int32_t T) {

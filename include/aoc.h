@@ -169,6 +169,27 @@ int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, const double 
                    double *x_new, double *u_new, double *J_new, double *stepsize, int32_t *ntrials,
                    int32_t *status, void *scratch);
 
+/* lqr_tracking.lqr_tracking (lqr_tracking.py:245-283): linearise about (x_opt,u_opt), non-augmented
+ * Riccati/gain recursion with the constant weights QQt,RRt,QQT of `prob` and S = 0
+ * (lqr_tracking.py:276), then the closed-loop nonlinear rollout u = u_opt + K (x - x_opt) from
+ * x0_reg (= x_opt[:,0] + perturbation, [ntiles][6][64]).  Kgain: tiled C=12 (row 0 then row 1 of the
+ * 2x6 gain; sample T-1 zero).  x_reg/u_reg/x0_reg may be NULL (gains only). */
+int aoc_lqr_tracking(const aoc_problem *prob, const double *x_opt, const double *u_opt, const double *x0_reg,
+                     double *Kgain, double *x_reg, double *u_reg, int32_t *status);
+
+/* optcon.ltv_LQR(AAin,BBin,QQin,RRin,SSin,QQfin,TT,x0,qq,rr,qqf)  (optcon.py:533-771; identical copy
+ * lqr_tracking.py:6-242) for nb independent problems with caller-supplied per-stage matrices, in
+ * the reference's order of operations; augmented != 0 selects the affine (7x7) form (q, r, qf may
+ * then be NULL = zeros).  Time-major per problem: A [nb][T][36], Bm [nb][T][12] (6x2), Q [nb][T][36],
+ * R [nb][T][4], S [nb][T][12] (2x6), Qf [nb][36], x0 [nb][6], q [nb][T][6], r [nb][T][2], qf [nb][6].
+ * Outputs: KK [nb][T][2n], PP [nb][T][n*n], xx [nb][T][6], uu [nb][T][2] with n = 6 or 7;
+ * nreg[nb] = stages regularised (optcon.py:745-749), nsing[nb] = singular M met.  Generic, not a
+ * throughput path (the Newton iteration uses aoc_backward/aoc_forward). */
+int aoc_ltv_lqr(int32_t nb, int32_t T, int32_t augmented, const double *A, const double *Bm, const double *Q,
+                const double *R, const double *S, const double *Qf, const double *x0, const double *q,
+                const double *r, const double *qf, double *KK, double *PP, double *xx, double *uu,
+                int32_t *nreg, int32_t *nsing, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Iteration level.  Workspace: caller-allocated device memory of aoc_workspace_bytes(B,T) bytes.
  * --------------------------------------------------------------------------------------------- */
