@@ -5,6 +5,7 @@ numerical operation of the hot path is a HIP kernel of libaoc_hip.so.  Arrays at
 reference's per-trajectory conventions stacked over the batch: xx (B,6,T), uu (B,2,T), float64.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -186,6 +187,7 @@ class NewtonBatchSolver:
         self.ntrials = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         self.status = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         self.x0 = torch.zeros((self.nt, 6, TILE), dtype=torch.float64, device=dev)
+        self.n_spec = int(os.environ.get("AOC_NSPEC", "2"))  # Armijo trials riding along in the forward pass
         self.cur = 0      # index of the buffer holding the current iterate
         self.kk = 0       # outer-iteration index of the current iterate
         self.jcur = 0
@@ -256,14 +258,17 @@ class NewtonBatchSolver:
         check(lib().aoc_backward(C.byref(p), int(kk > prm.hessian_switch), _ptr(self.xb[c]), _ptr(self.ub[c]),
                                  _ptr(Kt), _ptr(g), None, _ptr(self.status)), "aoc_backward")
         ev[1].record(st)
-        check(lib().aoc_forward(C.byref(p), prm.stepsize_0, _ptr(self.xb[c]), _ptr(self.ub[c]), _ptr(self.x0),
+        nsp = self.n_spec
+        Jt = self.ws[nel14 + 2 * nel2:nel14 + 2 * nel2 + 3 * self.Bp]
+        scratch = self.ws[nel14 + 2 * nel2 + 3 * self.Bp:]
+        check(lib().aoc_forward(C.byref(p), C.byref(prm), nsp, _ptr(self.xb[c]), _ptr(self.ub[c]), _ptr(self.x0),
                                 _ptr(Kt), _ptr(g), _ptr(du), _ptr(self.descent), None, None,
-                                _ptr(self.J[jn]), _ptr(self.status)), "aoc_forward")
+                                _ptr(Jt), _ptr(self.status)), "aoc_forward")
         ev[2].record(st)
-        check(lib().aoc_linesearch(C.byref(p), C.byref(prm), _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
-                                   _ptr(self.J[jc]), _ptr(self.descent), _ptr(self.J[jn]), _ptr(self.xb[n]),
+        check(lib().aoc_linesearch(C.byref(p), C.byref(prm), nsp, _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
+                                   _ptr(self.J[jc]), _ptr(self.descent), _ptr(Jt), _ptr(self.xb[n]),
                                    _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.stepsize), _ptr(self.ntrials),
-                                   _ptr(self.status), _ptr(self.ws[nel14 + 2 * nel2:])), "aoc_linesearch")
+                                   _ptr(self.status), _ptr(scratch)), "aoc_linesearch")
         ev[3].record(st)
         self.cur, self.jcur, self.kk = n, jn, kk + 1
         return ev
@@ -293,7 +298,7 @@ class NewtonBatchSolver:
                 hist.append(self.scalars())
         return hist
 
-    def solve(self, verbose=False):
+    def solve(self, verbose=False, callback=None):
         """NewtonMethod.optimize semantics per trajectory (reference optcon.py:415-505):
         iterate kk = 0..max_iters-2; a trajectory stops at the first kk with descent >= term_cond and
         then returns iterate kk-1 (python index -1 = an all-zero history slot when kk == 0); without
@@ -324,6 +329,8 @@ class NewtonBatchSolver:
                 # kk == 0: xx[:,:,-1] is the untouched, all-zero last history slot
                 self.status |= conv.to(torch.int32) * _lib.ST_CONVERGED
                 active = active & ~conv
+            if callback is not None:
+                callback(kk, self.scalars())
             if verbose:
                 s = self.scalars()
                 print("Iter = %d\t Descent = %r\t Cost = %r\t active = %d" %
@@ -404,10 +411,56 @@ def backward_forward(problem, xx, uu, full_hessian, stepsize_0=1.0):
     p = problem.c_problem(B)
     check(lib().aoc_backward(C.byref(p), int(bool(full_hessian)), _ptr(xt), _ptr(ut), _ptr(Kt), _ptr(g), _ptr(lm0),
                              _ptr(st)), "aoc_backward")
-    check(lib().aoc_forward(C.byref(p), float(stepsize_0), _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(g), _ptr(du),
+    prm = make_params(stepsize_0=stepsize_0)
+    check(lib().aoc_forward(C.byref(p), C.byref(prm), 1, _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(g), _ptr(du),
                             _ptr(desc), _ptr(xn), _ptr(un), _ptr(Jn), _ptr(st)), "aoc_forward")
     KK = unpack(Kt, B).cpu().numpy().reshape(B, 2, 7, T)
     return dict(KK=KK, g=unpack(g, B).cpu().numpy(), du=unpack(du, B).cpu().numpy(),
                 descent=desc[:B].cpu().numpy(), lmbd0=lm0.permute(0, 2, 1).reshape(-1, 6)[:B].cpu().numpy(),
                 xx_new=unpack(xn, B).cpu().numpy(), uu_new=unpack(un, B).cpu().numpy(),
                 J_new=Jn[:B].cpu().numpy(), status=st[:B].cpu().numpy())
+
+
+def lqr_tracking_batch(problem, xx_opt, uu_opt, delta):
+    """lqr_tracking.lqr_tracking for B trajectories (reference lqr_tracking.py:245-283).
+    problem carries the tracking weights QQt,RRt,QQT (reference lqr_tracking.py:324-328).
+    xx_opt (B,6,T), uu_opt (B,2,T), delta (6,) or (B,6) -> xx_reg (B,6,T), uu_reg (B,2,T), KK (B,2,6,T)."""
+    torch = _torch()
+    dev = problem.device
+    xx_opt = np.asarray(xx_opt, dtype=np.float64)
+    B, T = xx_opt.shape[0], problem.T
+    nt = ntiles(B)
+    xt, ut = pack(xx_opt, dev), pack(uu_opt, dev)
+    x0r = xx_opt[:, :, 0] + np.broadcast_to(np.asarray(delta, dtype=np.float64), (B, 6))  # lqr_tracking.py:265
+    x0t = pack_vec(x0r, dev)
+    Kg = alloc_tiled(B, T, 12, dev)
+    xr, ur = alloc_tiled(B, T, 6, dev), alloc_tiled(B, T, 2, dev)
+    st = torch.zeros(nt * TILE, dtype=torch.int32, device=dev)
+    p = problem.c_problem(B)
+    check(lib().aoc_lqr_tracking(C.byref(p), _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kg), _ptr(xr), _ptr(ur), _ptr(st)),
+          "aoc_lqr_tracking")
+    KK = unpack(Kg, B).cpu().numpy().reshape(B, 2, 6, T)
+    return unpack(xr, B).cpu().numpy(), unpack(ur, B).cpu().numpy(), KK, st[:B].cpu().numpy()
+
+
+def ltv_lqr_batch(AA, BB, QQ, RR, SS, QQf, x0, qq=None, rr=None, qqf=None, device="cuda:0"):
+    """Generic ltv_LQR for nb problems (reference optcon.py:533-771).  Time-major inputs per problem:
+    AA (nb,T,6,6), BB (nb,T,6,2), QQ (nb,T,6,6), RR (nb,T,2,2), SS (nb,T,2,6), QQf (nb,6,6), x0 (nb,6),
+    affine terms qq (nb,T,6), rr (nb,T,2), qqf (nb,6) or None.  Returns KK (nb,T,2,n), PP (nb,T,n,n),
+    xx (nb,T,6), uu (nb,T,2), nreg (nb,), nsing (nb,)."""
+    torch = _torch()
+    aug = qq is not None or rr is not None or qqf is not None  # optcon.py:614
+    n = 7 if aug else 6
+    d = lambda a: None if a is None else _dev_f64(a, device)
+    A, Bm, Q, R, S, Qf, X0 = (d(a) for a in (AA, BB, QQ, RR, SS, QQf, x0))
+    nb, T = A.shape[0], A.shape[1]
+    q, r, qf = d(qq), d(rr), d(qqf)
+    mk = lambda *s: torch.empty(s, dtype=torch.float64, device=A.device)
+    KK, PP, xx, uu = mk(nb, T, 2, n), mk(nb, T, n, n), mk(nb, T, 6), mk(nb, T, 2)
+    nreg = torch.zeros(nb, dtype=torch.int32, device=A.device)
+    nsing = torch.zeros(nb, dtype=torch.int32, device=A.device)
+    st = C.c_void_p(torch.cuda.current_stream(A.device).cuda_stream)
+    check(lib().aoc_ltv_lqr(nb, T, int(aug), _ptr(A), _ptr(Bm), _ptr(Q), _ptr(R), _ptr(S), _ptr(Qf), _ptr(X0), _ptr(q),
+                            _ptr(r), _ptr(qf), _ptr(KK), _ptr(PP), _ptr(xx), _ptr(uu), _ptr(nreg), _ptr(nsing), st),
+          "aoc_ltv_lqr")
+    return tuple(t.cpu().numpy() for t in (KK, PP, xx, uu, nreg, nsing))

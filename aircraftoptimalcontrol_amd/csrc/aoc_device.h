@@ -50,7 +50,6 @@ struct SC { double sg, cg, sa, ca; };
 // mostly on a Payne-Hanek path these arguments never take; this one is ~45 and has no control flow,
 // so the two calls per stage interleave.  Larger or non-finite arguments fall back to the library.
 __device__ __forceinline__ void sincos_fast(double x, double* sp, double* cp) {
-    if (!(__builtin_fabs(x) < 1048576.0)) { sincos(x, sp, cp); return; }
     const double n = __builtin_rint(x * 6.36619772367581382433e-01);          // x * 2/pi
     double r = __builtin_fma(-n, 1.57079632679489655800e+00, x);               // pi/2, exact step
     r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
@@ -81,11 +80,18 @@ __device__ __forceinline__ void sincos_fast(double x, double* sp, double* cp) {
     *cp = c;
 }
 
+// Both angle pairs of a stage.  The two fast evaluations are independent straight-line code (they
+// interleave); ONE rarely-taken branch afterwards redoes them with the library for huge or
+// non-finite arguments.
 __device__ __forceinline__ SC trig(double th, double ga) {
     SC s;
-    double al = th - ga;
+    const double al = th - ga;
     sincos_fast(ga, &s.sg, &s.cg);
     sincos_fast(al, &s.sa, &s.ca);
+    if (!(__builtin_fabs(ga) < 1048576.0 && __builtin_fabs(al) < 1048576.0)) {
+        sincos(ga, &s.sg, &s.cg);
+        sincos(al, &s.sa, &s.ca);
+    }
     return s;
 }
 

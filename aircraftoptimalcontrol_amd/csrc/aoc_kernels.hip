@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/aoc.h"
@@ -181,7 +182,7 @@ __device__ __forceinline__ double rollout(const KConst& k, const double* __restr
                 u1 = uc1 + a * dc1;
             }
             JJ += stage_cost<DIAG>(k, xs, u0, u1, ref + (size_t)t * 8, q, r);
-            if (!(xs[2] > 0.0)) flags |= AOC_ST_VNONPOS;
+            if (WRITE && !(xs[2] > 0.0)) flags |= AOC_ST_VNONPOS;  // trials are silent: only the update reports
             const SC s = trig(xs[3], xs[5]);
             step_state(k, xs, u0, u1, s, xn);
             if (WRITE && wmask) {
@@ -328,25 +329,36 @@ __global__ __launch_bounds__(TILE) void k_backward(KConst k, const double* __res
     if (status && flags) status[tile * TILE + lane] |= flags;
 }
 
-// Forward pass (see aoc_forward in include/aoc.h).
-template <bool DIAG, bool WRITE>
-__global__ __launch_bounds__(TILE) void k_forward(KConst k, double alpha0, const double* __restrict__ ref,
+// Forward pass (see aoc_forward in include/aoc.h).  NSPEC = number of Armijo candidate steps
+// (alpha_0 .. alpha_{NSPEC-1}) whose trial rollouts ride along: the pass is bound by the K~ stream
+// from HBM, so a second serial chain in the same lane is nearly free and saves a whole
+// latency-bound trial round later.
+template <bool DIAG, int NSPEC, bool WRITE>
+__global__ __launch_bounds__(TILE) void k_forward(KConst k, aoc_params prm, const double* __restrict__ ref,
                                                   const double* __restrict__ x, const double* __restrict__ u,
                                                   const double* __restrict__ x0, const double* __restrict__ Kt,
                                                   const double* __restrict__ g, double* __restrict__ du_out,
                                                   double* __restrict__ descent, double* __restrict__ x_new,
-                                                  double* __restrict__ u_new, double* __restrict__ J_new,
+                                                  double* __restrict__ u_new, double* __restrict__ J_trial,
                                                   int* __restrict__ status) {
     const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane, T = k.T;
-    double dx[6], xp[6], xpn[6], q[6], r[2];
+    const int Bp = k.ntiles * TILE;
+    double dx[6], xp[NSPEC][6], q[6], r[2], JJ[NSPEC], alpha[NSPEC];
     int flags = 0;
+    alpha[0] = prm.stepsize_0;
+#pragma unroll
+    for (int j = 1; j < NSPEC; j++) alpha[j] = prm.beta * alpha[j - 1];  // optcon.py:270
 #pragma unroll
     for (int c = 0; c < 6; c++) {
         dx[c] = 0.0;  // ltv_LQR is called with x0 = 0 (optcon.py:470)
-        xp[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
-        if (WRITE) x_new[tix<6>(tile, T, 0, c, lane)] = xp[c];
+        const double v = x0[((size_t)tile * 6 + c) * TILE + lane];
+#pragma unroll
+        for (int j = 0; j < NSPEC; j++) xp[j][c] = v;
+        if (WRITE) x_new[tix<6>(tile, T, 0, c, lane)] = v;
     }
-    double desc = 0.0, JJ = 0.0;
+#pragma unroll
+    for (int j = 0; j < NSPEC; j++) JJ[j] = 0.0;
+    double desc = 0.0;
     // software prefetch of stage t+1 operands
     double Kn[14], gn0, gn1, xn[6], un0, un1;
 #pragma unroll
@@ -389,36 +401,41 @@ __global__ __launch_bounds__(TILE) void k_forward(KConst k, double alpha0, const
         }
         du_out[tix<2>(tile, T, t, 0, lane)] = d0;
         du_out[tix<2>(tile, T, t, 1, lane)] = d1;
-        // first Armijo trial, step alpha0 (optcon.py:250-264)
-        double u0, u1;
-        {
+        // Armijo trials alpha_0 .. alpha_{NSPEC-1} (optcon.py:250-264), independent chains
+#pragma unroll
+        for (int j = 0; j < NSPEC; j++) {
+            double u0, u1, xpn[6];
+            {
 #pragma clang fp contract(off)
-            u0 = uc0 + alpha0 * d0;
-            u1 = uc1 + alpha0 * d1;
-        }
-        JJ += stage_cost<DIAG>(k, xp, u0, u1, ref + (size_t)t * 8, q, r);
-        if (!(xp[2] > 0.0)) flags |= AOC_ST_VNONPOS;
-        const SC s2 = trig(xp[3], xp[5]);
-        step_state(k, xp, u0, u1, s2, xpn);
-        if (WRITE) {
-            u_new[tix<2>(tile, T, t, 0, lane)] = u0;
-            u_new[tix<2>(tile, T, t, 1, lane)] = u1;
+                u0 = uc0 + alpha[j] * d0;
+                u1 = uc1 + alpha[j] * d1;
+            }
+            JJ[j] += stage_cost<DIAG>(k, xp[j], u0, u1, ref + (size_t)t * 8, q, r);
+            const SC s2 = trig(xp[j][3], xp[j][5]);
+            step_state(k, xp[j], u0, u1, s2, xpn);
+            if (WRITE && j == 0) {
+                u_new[tix<2>(tile, T, t, 0, lane)] = u0;
+                u_new[tix<2>(tile, T, t, 1, lane)] = u1;
 #pragma unroll
-            for (int c = 0; c < 6; c++) x_new[tix<6>(tile, T, t + 1, c, lane)] = xpn[c];
-        }
+                for (int c = 0; c < 6; c++) x_new[tix<6>(tile, T, t + 1, c, lane)] = xpn[c];
+            }
 #pragma unroll
-        for (int c = 0; c < 6; c++) xp[c] = xpn[c];
+            for (int c = 0; c < 6; c++) xp[j][c] = xpn[c];
+        }
     }
-    JJ += term_cost<DIAG>(k, xp, ref + (size_t)(T - 1) * 8, q);
     du_out[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
     du_out[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
     if (WRITE) {
         u_new[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
         u_new[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
     }
-    if (JJ != JJ || JJ - JJ != 0.0 || desc != desc || desc - desc != 0.0) flags |= AOC_ST_NAN;
+#pragma unroll
+    for (int j = 0; j < NSPEC; j++) {
+        JJ[j] += term_cost<DIAG>(k, xp[j], ref + (size_t)(T - 1) * 8, q);
+        J_trial[(size_t)j * Bp + b] = JJ[j];
+    }
+    if (desc != desc || desc - desc != 0.0) flags |= AOC_ST_NAN;
     descent[b] = desc;
-    J_new[b] = JJ;
     if (status && flags) status[b] |= flags;
 }
 
@@ -699,23 +716,36 @@ struct LsScratch {
     LsState* st;
 };
 
-__global__ __launch_bounds__(TILE) void k_ls_init(aoc_params prm, const double* __restrict__ J_cur,
+__global__ __launch_bounds__(TILE) void k_ls_init(aoc_params prm, int nspec, int Bp, const double* __restrict__ J_cur,
                                                   const double* __restrict__ descent,
-                                                  const double* __restrict__ J_trial0, double* __restrict__ stepsize,
+                                                  const double* __restrict__ J_trial, double* __restrict__ stepsize,
                                                   int* __restrict__ ntrials, LsScratch sc) {
     const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane;
-    const bool rej = armijo_reject(J_trial0[b], J_cur[b], prm.cc, prm.stepsize_0, descent[b]);
-    const unsigned long long m = __ballot(rej);
-    stepsize[b] = prm.stepsize_0;
-    ntrials[b] = 1;
+    // verdicts of the nspec trials evaluated by aoc_forward, in the reference's order
+    const double JP = J_cur[b], d = descent[b];
+    double a = prm.stepsize_0;
+    bool searching = true;
+    int ntr = 0;
+    double acc = a;
+    for (int j = 0; j < nspec && j < prm.armijo_maxiters; j++) {
+        if (searching) {
+            ntr = j + 1;
+            if (!armijo_reject(J_trial[(size_t)j * Bp + b], JP, prm.cc, a, d)) { searching = false; acc = a; }
+        }
+        a = prm.beta * a;
+    }
+    const unsigned long long m = __ballot(searching);
+    stepsize[b] = acc;
+    ntrials[b] = ntr;
     sc.first_ok[b] = LS_NOT_FOUND;
     if (lane == 0) sc.mask[tile] = m;
     if (tile == 0 && lane == 0) {
-        double a = prm.stepsize_0;
-        sc.st->alpha[0] = a;
-        for (int i = 1; i <= prm.armijo_maxiters; i++) { a = prm.beta * a; sc.st->alpha[i] = a; }  // optcon.py:270
-        sc.st->r_next = 1;
-        sc.st->r_start = 1;
+        double al = prm.stepsize_0;
+        sc.st->alpha[0] = al;
+        for (int i = 1; i <= prm.armijo_maxiters; i++) { al = prm.beta * al; sc.st->alpha[i] = al; }  // optcon.py:270
+        const int done = nspec < prm.armijo_maxiters ? nspec : prm.armijo_maxiters;
+        sc.st->r_next = done;
+        sc.st->r_start = done;
         sc.st->K = 0;
         sc.st->count = 0;
         sc.st->nw = 0;
@@ -753,7 +783,7 @@ __global__ __launch_bounds__(TILE) void k_ls_resolve(LsScratch sc, double* __res
 // One workgroup: exclusive prefix sum of the per-tile popcounts and the plan of the next round:
 // K candidate steps per searching trajectory, as many as keep the round within `wcap` wavefronts,
 // but not more than round+1 (rejection thins out geometrically: deep speculation only pays late).
-__global__ __launch_bounds__(1024) void k_ls_plan(int ntiles, int maxiters, int wcap, LsScratch sc) {
+__global__ __launch_bounds__(1024) void k_ls_plan(int ntiles, int maxiters, int wcap, int kgrow, LsScratch sc) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -788,7 +818,7 @@ __global__ __launch_bounds__(1024) void k_ls_plan(int ntiles, int maxiters, int 
         int K = 0;
         if (count > 0 && r_done < maxiters) {
             K = wcap / nw;
-            if (K > round + 1) K = round + 1;
+            if (K > kgrow * round + 1) K = kgrow * round + 1;
             if (K < 1) K = 1;
             if (K > maxiters - r_done) K = maxiters - r_done;
         }
@@ -1037,21 +1067,29 @@ int aoc_backward(const aoc_problem* p, int32_t full_hessian, const double* x, co
     return check_launch("k_backward");
 }
 
-int aoc_forward(const aoc_problem* p, double alpha0, const double* x, const double* u, const double* x0,
-                const double* Kt, const double* g, double* du, double* descent, double* x_new, double* u_new,
-                double* J_new, int32_t* status) {
+int aoc_forward(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const double* x, const double* u,
+                const double* x0, const double* Kt, const double* g, double* du, double* descent, double* x_new,
+                double* u_new, double* J_trial, int32_t* status) {
     int rc = check_problem(p);
     if (rc) return rc;
-    if (!x || !u || !x0 || !Kt || !g || !du || !descent || !J_new) return AOC_EINVAL;
+    if (!prm || !x || !u || !x0 || !Kt || !g || !du || !descent || !J_trial) return AOC_EINVAL;
     if ((x_new == nullptr) != (u_new == nullptr)) return AOC_EINVAL;
+    if (n_spec < 1 || n_spec > 3) return AOC_EINVAL;
     KConst k = make_const(p);
     hipStream_t st = (hipStream_t)p->stream;
     const bool w = x_new != nullptr;
-#define LAUNCH_FW(D, W)                                                                                          \
-    hipLaunchKernelGGL((k_forward<D, W>), dim3(k.ntiles), dim3(TILE), 0, st, k, alpha0, p->ref, x, u, x0, Kt, g, du, \
-                       descent, x_new, u_new, J_new, status)
-    if (k.diag) { if (w) LAUNCH_FW(true, true); else LAUNCH_FW(true, false); }
-    else { if (w) LAUNCH_FW(false, true); else LAUNCH_FW(false, false); }
+#define LAUNCH_FW(D, N, W)                                                                                         \
+    hipLaunchKernelGGL((k_forward<D, N, W>), dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, p->ref, x, u, x0, Kt, g, du, \
+                       descent, x_new, u_new, J_trial, status)
+#define LAUNCH_FW_N(D, W)                                        \
+    do {                                                         \
+        if (n_spec == 1) LAUNCH_FW(D, 1, W);                     \
+        else if (n_spec == 2) LAUNCH_FW(D, 2, W);                \
+        else LAUNCH_FW(D, 3, W);                                 \
+    } while (0)
+    if (k.diag) { if (w) LAUNCH_FW_N(true, true); else LAUNCH_FW_N(true, false); }
+    else { if (w) LAUNCH_FW_N(false, true); else LAUNCH_FW_N(false, false); }
+#undef LAUNCH_FW_N
 #undef LAUNCH_FW
     return check_launch("k_forward");
 }
@@ -1064,15 +1102,17 @@ size_t aoc_linesearch_scratch_bytes(int32_t B) {
            align_up(nt * TILE * sizeof(int), 16) + align_up(sizeof(LsState), 16);
 }
 
-int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, const double* u, const double* x0, const double* du,
-                   const double* J_cur, const double* descent, const double* J_trial0, double* x_new, double* u_new,
-                   double* J_new, double* stepsize, int32_t* ntrials, int32_t* status, void* scratch) {
+int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const double* u, const double* x0,
+                   const double* du, const double* J_cur, const double* descent, const double* J_trial0,
+                   double* x_new, double* u_new, double* J_new, double* stepsize, int32_t* ntrials, int32_t* status,
+                   void* scratch) {
     int rc = check_problem(p);
     if (rc) return rc;
     if (!prm || !u || !x0 || !du || !J_cur || !descent || !J_trial0 || !x_new || !u_new || !J_new || !stepsize ||
         !ntrials || !scratch)
         return AOC_EINVAL;
     if (prm->armijo_maxiters < 1 || prm->armijo_maxiters >= LS_MAX_STEPS) return AOC_EINVAL;
+    if (n_spec < 1 || n_spec > 3) return AOC_EINVAL;
     KConst k = make_const(p);
     hipStream_t st = (hipStream_t)p->stream;
     const size_t nt = (size_t)k.ntiles;
@@ -1082,12 +1122,15 @@ int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, const double* u,
     sc.prefix = (int*)base;               base += align_up((nt + 1) * sizeof(int), 16);
     sc.first_ok = (int*)base;             base += align_up(nt * TILE * sizeof(int), 16);
     sc.st = (LsState*)base;
-    // wavefronts a trial round may occupy: one per SIMD (256 CUs x 4 SIMDs), at least one per tile
-    const int wcap = k.ntiles > 1024 ? k.ntiles : 1024;
-    hipLaunchKernelGGL(k_ls_init, dim3(k.ntiles), dim3(TILE), 0, st, *prm, J_cur, descent, J_trial0, stepsize, ntrials, sc);
-    for (int r = 1; r < prm->armijo_maxiters; r++) {
-        if (r > 1) hipLaunchKernelGGL(k_ls_resolve, dim3(k.ntiles), dim3(TILE), 0, st, sc, stepsize, ntrials);
-        hipLaunchKernelGGL(k_ls_plan, dim3(1), dim3(1024), 0, st, k.ntiles, prm->armijo_maxiters, wcap, sc);
+    // wavefronts a trial round may occupy: about one per SIMD (256 CUs x 4 SIMDs), at least one per tile
+    static const int wcap_env = getenv("AOC_LS_WCAP") ? atoi(getenv("AOC_LS_WCAP")) : 1024;
+    static const int kgrow_env = getenv("AOC_LS_KGROW") ? atoi(getenv("AOC_LS_KGROW")) : 1;
+    const int wcap = k.ntiles > wcap_env ? k.ntiles : wcap_env;
+    hipLaunchKernelGGL(k_ls_init, dim3(k.ntiles), dim3(TILE), 0, st, *prm, n_spec, k.ntiles * TILE, J_cur, descent,
+                       J_trial0, stepsize, ntrials, sc);
+    for (int r = n_spec; r < prm->armijo_maxiters; r++) {
+        if (r > n_spec) hipLaunchKernelGGL(k_ls_resolve, dim3(k.ntiles), dim3(TILE), 0, st, sc, stepsize, ntrials);
+        hipLaunchKernelGGL(k_ls_plan, dim3(1), dim3(1024), 0, st, k.ntiles, prm->armijo_maxiters, wcap_env, kgrow_env, sc);
         if (k.diag)
             hipLaunchKernelGGL(k_ls_trial<true>, dim3(wcap), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du, J_cur,
                                descent, sc);
@@ -1136,8 +1179,9 @@ int aoc_ltv_lqr(int32_t nb, int32_t T, int32_t augmented, const double* A, const
 }
 
 size_t aoc_workspace_bytes(int32_t B, int32_t T) {
-    // K~ (14) + g (2) + du (2) components, tiled; then the line-search scratch
-    return aoc_tiled_elems(B, T, 18) * sizeof(double) + aoc_linesearch_scratch_bytes(B);
+    // K~ (14) + g (2) + du (2) components, tiled; trial costs [3][ntiles*64]; then the line-search scratch
+    return aoc_tiled_elems(B, T, 18) * sizeof(double) + 3 * (size_t)aoc_ntiles(B) * TILE * sizeof(double) +
+           aoc_linesearch_scratch_bytes(B);
 }
 
 int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, const double* x, const double* u,
@@ -1151,12 +1195,13 @@ int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, 
     double* du = g + aoc_tiled_elems(p->B, p->T, 2);
     rc = aoc_backward(p, kk > prm->hessian_switch, x, u, Kt, g, nullptr, status);
     if (rc) return rc;
-    // J_new doubles as the holder of the first trial's cost J'(stepsize_0) until the line search overwrites it
-    rc = aoc_forward(p, prm->stepsize_0, x, u, x0, Kt, g, du, descent, nullptr, nullptr, J_new, status);
+    double* J_trial = du + aoc_tiled_elems(p->B, p->T, 2);
+    void* scratch = (void*)(J_trial + 3 * (size_t)aoc_ntiles(p->B) * TILE);
+    static const int nspec = getenv("AOC_NSPEC") ? atoi(getenv("AOC_NSPEC")) : 2;
+    rc = aoc_forward(p, prm, nspec, x, u, x0, Kt, g, du, descent, nullptr, nullptr, J_trial, status);
     if (rc) return rc;
-    void* scratch = (void*)(du + aoc_tiled_elems(p->B, p->T, 2));
-    return aoc_linesearch(p, prm, u, x0, du, J_cur, descent, J_new, x_new, u_new, J_new, stepsize, ntrials, status,
-                          scratch);
+    return aoc_linesearch(p, prm, nspec, u, x0, du, J_cur, descent, J_trial, x_new, u_new, J_new, stepsize, ntrials,
+                          status, scratch);
 }
 
 }  // extern "C"

@@ -1,0 +1,167 @@
+"""Drop-in for the reference module `optcon` on the HIP library.
+
+    from optcon import NewtonMethod, GradientMethod, ltv_LQR
+
+Same constructor arguments, method names, return values and stdout lines as the reference
+(file:line cited per method).  The Dynamics/Cost objects passed in must be the drop-in
+`aircraft_simplified.Dynamics` / `Cost` (the HIP kernels implement that model and a quadratic cost);
+anything else raises TypeError.  Differences, all outside the numerical path: no Matplotlib figures
+are opened (histories are kept on the object instead: `.JJ`, `.descent`, `.stepsizes`), and
+`GradientMethod.optimize`, which raises TypeError in the reference (8 arguments passed to a
+9-parameter method, optcon.py:125 vs :204), raises NotImplementedError here.
+"""
+import numpy as np
+
+from aircraftoptimalcontrol_amd import batch as _b
+
+
+def _model_of(dyn):
+    need = ("cd0", "cda", "cla", "m", "g", "S", "rho", "J", "dt", "ns", "ni")
+    if not all(hasattr(dyn, a) for a in need) or dyn.ns != 6 or dyn.ni != 2:
+        raise TypeError("the HIP path implements the 6-state/2-input aircraft of aircraft_simplified.Dynamics; "
+                        "got %r" % (dyn,))
+    return _b.Model(dyn.cd0, dyn.cda, dyn.cla, float(dyn.m), dyn.g, dyn.S, dyn.rho, dyn.J, float(dyn.dt))
+
+
+def _weights_of(cst):
+    if not all(hasattr(cst, a) for a in ("QQt", "RRt", "QQT")):
+        raise TypeError("the HIP path implements the quadratic cost of aircraft_simplified.Cost; got %r" % (cst,))
+    return cst.QQt, cst.RRt, cst.QQT
+
+
+class GradientMethod:
+    """Constructor, armijo_stepsize and get_update of the reference class (optcon.py:7-327)."""
+
+    def __init__(self, Dynamics, cost, xx_ref, uu_ref, max_iters=200, stepsize_0=1e-2, cc=0.5, beta=0.7,
+                 armijo_maxiters=20, term_cond=1e-6, visu_armijo=False):
+        self.dyn, self.cst = Dynamics, cost
+        self.ns, self.ni = self.dyn.ns, self.dyn.ni
+        self.xx_ref, self.uu_ref = xx_ref, uu_ref
+        self.max_iters, self.stepsize_0 = max_iters, stepsize_0
+        self.cc, self.beta = cc, beta
+        self.term_cond = term_cond            # ignored by the reference's optimize (optcon.py:368)
+        self.armijo_maxiters = armijo_maxiters
+        self.visu_armijo = visu_armijo
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _problem(self, TT):
+        Q, R, QT = _weights_of(self.cst)
+        xr = np.asarray(self.xx_ref, dtype=np.float64)[:, :TT]
+        ur = np.asarray(self.uu_ref, dtype=np.float64)[:, :TT]
+        return _b.BatchProblem(Q, R, QT, xr, ur, float(self.dyn.dt), model=_model_of(self.dyn))
+
+    def _params(self):
+        return _b.make_params(max_iters=self.max_iters, stepsize_0=self.stepsize_0, cc=self.cc, beta=self.beta,
+                              armijo_maxiters=self.armijo_maxiters, term_cond=-1e-6)
+
+    def optimize(self, xx_init, uu_init, tf, dt):
+        raise NotImplementedError("GradientMethod.optimize is unusable in the reference (TypeError at optcon.py:125); "
+                                  "use NewtonMethod")
+
+    def get_update(self, stepsize, uu, deltau, x0):
+        """-> xx_temp (ns,TT), uu_temp (ni,TT)   (optcon.py:176-200)"""
+        uu = np.asarray(uu, dtype=np.float64)
+        prob = self._problem(uu.shape[1])
+        xx, un, _, _ = _b.rollout_cost(prob, np.asarray(x0, dtype=np.float64)[None], uu[None],
+                                       np.asarray(deltau, dtype=np.float64)[None], [float(stepsize)])
+        return xx[0], un[0]
+
+    def armijo_stepsize(self, uu, deltau, xx_ref, uu_ref, x0, TT, JJ, descent, JP):
+        """-> stepsize   (optcon.py:204-327); prints 'Armijo stepsize = s' on acceptance (:272).
+        All candidate steps are rolled out in one launch; the first accepted index is returned, and on
+        exhaustion the never-evaluated stepsize_0*beta^armijo_maxiters (:327)."""
+        uu = np.asarray(uu, dtype=np.float64)
+        Q, R, QT = _weights_of(self.cst)
+        prob = _b.BatchProblem(Q, R, QT, np.asarray(xx_ref, dtype=np.float64)[:, :TT],
+                               np.asarray(uu_ref, dtype=np.float64)[:, :TT], float(self.dyn.dt),
+                               model=_model_of(self.dyn))
+        n = int(self.armijo_maxiters)
+        steps = [self.stepsize_0]
+        for _ in range(n):
+            steps.append(self.beta * steps[-1])
+        _, _, J, _ = _b.rollout_cost(prob, np.repeat(np.asarray(x0, dtype=np.float64)[None], n, 0),
+                                     np.repeat(uu[None], n, 0),
+                                     np.repeat(np.asarray(deltau, dtype=np.float64)[None], n, 0),
+                                     np.array(steps[:n]), write=False)
+        JP, descent = float(np.squeeze(JP)), float(np.squeeze(descent))
+        for ii in range(n):
+            if not (J[ii] > JP + self.cc * steps[ii] * descent):
+                print('Armijo stepsize = {}'.format(steps[ii]))
+                return steps[ii]
+        return steps[n]
+
+
+class NewtonMethod(GradientMethod):
+    """NewtonMethod(...).optimize(xx_init, uu_init, tf, dt) -> xx_star (ns,TT), uu_star (ni,TT)
+    (optcon.py:329-529), one trajectory, on the batched HIP solver."""
+
+    def optimize(self, xx_init, uu_init, tf, dt):
+        TT = int(tf / dt)                                   # optcon.py:378
+        prob = self._problem(TT)
+        prm = self._params()
+        s = _b.NewtonBatchSolver(prob, 1, prm)
+        s.set_initial(np.asarray(xx_init, dtype=np.float64)[None, :, :TT], np.asarray(uu_init, dtype=np.float64)[None, :, :TT])
+        print('-*-*-*-*-*-')                                # optcon.py:410
+
+        exhausted = self.stepsize_0
+        for _ in range(int(self.armijo_maxiters)):
+            exhausted = self.beta * exhausted               # the step an exhausted search returns (optcon.py:327)
+
+        def echo(kk, sc):
+            if float(sc["stepsize"][0]) != exhausted:       # accepted trials print, exhausted searches do not
+                print('Armijo stepsize = {}'.format(float(sc["stepsize"][0])))   # optcon.py:272
+            print('Iter = {}\t Descent = {}\t Cost = {}'.format(kk, float(sc["descent"][0]), float(sc["cost"][0])))
+            print('term = {}'.format(-1e-06))               # optcon.py:497-498
+
+        r = s.solve(callback=echo)
+        h = r["history"]
+        self.JJ, self.descent, self.stepsizes = h["cost"][0], h["descent"][0], h["stepsize"][0]
+        self.iters, self.status = int(r["iters"][0]), int(r["status"][0])
+        return r["xx_star"][0], r["uu_star"][0]
+
+
+def ltv_LQR(AAin, BBin, QQin, RRin, SSin, QQfin, TT, x0, qq=None, rr=None, qqf=None):
+    """-> KK (ni, n, TT), PP (n, n, TT), xxout (ns, TT), uuout (ni, TT) with n = ns (+1 when any affine term is
+    given)   (optcon.py:533-771).  2-D inputs are broadcast over TT as in the reference (:552-608);
+    dimension mismatches print the reference's message and exit() (:585-596, :642-647)."""
+    def t3(a):
+        a = np.asarray(a, dtype=np.float64)
+        return a[:, :, None] if a.ndim == 2 else a
+    AA, BB, QQ, RR, SS = (t3(a) for a in (AAin, BBin, QQin, RRin, SSin))
+    ns, ni = AA.shape[1], BB.shape[1]
+    if QQ.shape[1] != ns:
+        print("Matrix Q does not match number of states"); exit()
+    if RR.shape[1] != ni:
+        print("Matrix R does not match number of inputs"); exit()
+    if SS.shape[1] != ns:
+        print("Matrix S does not match number of states"); exit()
+    if SS.shape[0] != ni:
+        print("Matrix S does not match number of inputs"); exit()
+    if ns != 6 or ni != 2:
+        raise ValueError("the HIP ltv_LQR is built for ns = 6, ni = 2")
+    rep = lambda a: a.repeat(TT, axis=2) if a.shape[2] < TT else a
+    AA, BB, QQ, RR, SS = (rep(a) for a in (AA, BB, QQ, RR, SS))
+    augmented = qq is not None or rr is not None or qqf is not None
+    q = r = qf = None
+    if augmented:
+        print("Augmented term!")                            # optcon.py:616
+        q = np.zeros(ns) if qq is None else np.asarray(qq, dtype=np.float64)
+        r = np.zeros(ni) if rr is None else np.asarray(rr, dtype=np.float64)
+        qf = np.zeros(ns) if qqf is None else np.asarray(qqf, dtype=np.float64)
+        q = q[:, None] if q.ndim == 1 else q
+        r = r[:, None] if r.ndim == 1 else r
+        if q.shape[0] != ns:
+            print("State affine term does not match states dimension"); exit()
+        if r.shape[0] != ni:
+            print("Input affine term does not match inputs dimension"); exit()
+        q = q.repeat(TT, axis=1) if q.shape[1] == 1 else q
+        r = r.repeat(TT, axis=1) if r.shape[1] == 1 else r
+    tm = lambda a: np.ascontiguousarray(np.moveaxis(a[..., :TT], -1, 0))[None]
+    KK, PP, xx, uu, _, nsing = _b.ltv_lqr_batch(tm(AA), tm(BB), tm(QQ), tm(RR), tm(SS),
+                                                np.asarray(QQfin, dtype=np.float64)[None],
+                                                np.asarray(x0, dtype=np.float64)[None],
+                                                None if q is None else tm(q), None if r is None else tm(r),
+                                                None if qf is None else qf[None])
+    if nsing[0]:
+        raise np.linalg.LinAlgError("Singular matrix")     # what np.linalg.inv raises in the reference
+    return (np.moveaxis(KK[0], 0, -1).copy(), np.moveaxis(PP[0], 0, -1).copy(), xx[0].T.copy(), uu[0].T.copy())

@@ -146,28 +146,30 @@ int aoc_backward(const aoc_problem *prob, int32_t full_hessian, const double *x,
                  double *Kt, double *g, double *lmbd0, int32_t *status);
 
 /* Forward pass: closed-loop linear rollout of ltv_LQR (optcon.py:756-762) giving du, the descent
- * sum (optcon.py:474-477), fused with the first Armijo trial (step alpha0 = stepsize_0): u' = u +
- * alpha0*du, nonlinear rollout x' from x0, cost J' (optcon.py:250-264).
- * Outputs: du (tiled C=2), descent[ntiles*64], J_trial0[ntiles*64] = J'(alpha0); x_new/u_new (tiled)
- * receive the trial trajectory when non-NULL (both or neither). */
-int aoc_forward(const aoc_problem *prob, double alpha0, const double *x, const double *u, const double *x0,
-                const double *Kt, const double *g, double *du, double *descent, double *x_new,
-                double *u_new, double *J_trial0, int32_t *status);
+ * sum (optcon.py:474-477), fused with the first n_spec (1..3) Armijo trials: for step
+ * alpha_j = stepsize_0*beta^j, u' = u + alpha_j*du, nonlinear rollout x' from x0, cost J'_j
+ * (optcon.py:250-264).  The pass is bound by the K~ stream, so trials 1.. ride along for free; the
+ * reference evaluates them one after the other, the verdict order is kept by aoc_linesearch.
+ * Outputs: du (tiled C=2), descent[ntiles*64], J_trial[n_spec][ntiles*64]; x_new/u_new (tiled)
+ * receive the alpha_0 trial trajectory when non-NULL (both or neither). */
+int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const double *x, const double *u,
+                const double *x0, const double *Kt, const double *g, double *du, double *descent,
+                double *x_new, double *u_new, double *J_trial, int32_t *status);
 
 /* Armijo back-tracking (optcon.py:243-273) and the final update (optcon.py:488-491).
  * Trial ii uses alpha_ii = stepsize_0*beta^ii and is accepted iff J'(alpha_ii) <= J_cur +
- * cc*alpha_ii*descent; trial 0 is judged from J_trial0 (written by aoc_forward).  Rejected
- * trajectories are compacted and searched in rounds; when few remain a round evaluates several
- * candidate steps of each at once (the accepted index is the first one that passes, as in the
- * reference's sequential loop).  On exhaustion the untested stepsize_0*beta^armijo_maxiters is used
- * (Q5).  Finally EVERY trajectory is rolled out with its step into x_new/u_new and J_new (may alias
- * J_trial0).  stepsize[b], ntrials[b] report the result.  armijo_maxiters <= 63.
- * scratch: device memory of aoc_linesearch_scratch_bytes(B) bytes. */
+ * cc*alpha_ii*descent; trials 0..n_spec-1 are judged from J_trial (written by aoc_forward).
+ * Trajectories still rejected are compacted and searched in rounds; when few remain a round
+ * evaluates several candidate steps of each at once (the accepted index is the first one that
+ * passes, as in the reference's sequential loop).  On exhaustion the untested
+ * stepsize_0*beta^armijo_maxiters is used (Q5).  Finally EVERY trajectory is rolled out with its
+ * step into x_new/u_new and J_new.  stepsize[b], ntrials[b] report the result.
+ * armijo_maxiters <= 63.  scratch: device memory of aoc_linesearch_scratch_bytes(B) bytes. */
 size_t aoc_linesearch_scratch_bytes(int32_t B);
-int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, const double *u, const double *x0,
-                   const double *du, const double *J_cur, const double *descent, const double *J_trial0,
-                   double *x_new, double *u_new, double *J_new, double *stepsize, int32_t *ntrials,
-                   int32_t *status, void *scratch);
+int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const double *u,
+                   const double *x0, const double *du, const double *J_cur, const double *descent,
+                   const double *J_trial, double *x_new, double *u_new, double *J_new, double *stepsize,
+                   int32_t *ntrials, int32_t *status, void *scratch);
 
 /* lqr_tracking.lqr_tracking (lqr_tracking.py:245-283): linearise about (x_opt,u_opt), non-augmented
  * Riccati/gain recursion with the constant weights QQt,RRt,QQT of `prob` and S = 0
