@@ -45,10 +45,11 @@ class GradientMethod:
 
     # -- helpers -------------------------------------------------------------------------------
     def _problem(self, TT):
+        mdl = _model_of(self.dyn)
         Q, R, QT = _weights_of(self.cst)
         xr = np.asarray(self.xx_ref, dtype=np.float64)[:, :TT]
         ur = np.asarray(self.uu_ref, dtype=np.float64)[:, :TT]
-        return _b.BatchProblem(Q, R, QT, xr, ur, float(self.dyn.dt), model=_model_of(self.dyn))
+        return _b.BatchProblem(Q, R, QT, xr, ur, float(self.dyn.dt), model=mdl)
 
     def _params(self):
         return _b.make_params(max_iters=self.max_iters, stepsize_0=self.stepsize_0, cc=self.cc, beta=self.beta,
