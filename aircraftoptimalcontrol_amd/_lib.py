@@ -46,7 +46,8 @@ class Model(C.Structure):
 
 class Problem(C.Structure):
     _fields_ = [("model", Model), ("QQt", C.c_double * 36), ("RRt", C.c_double * 4), ("QQT", C.c_double * 36),
-                ("B", C.c_int32), ("T", C.c_int32), ("ref", C.c_void_p), ("stream", C.c_void_p)]
+                ("B", C.c_int32), ("T", C.c_int32), ("x_in_f32", C.c_int32), ("x_out_f32", C.c_int32),
+                ("ref", C.c_void_p), ("stream", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -65,16 +66,18 @@ SYMBOLS = {
     "aoc_ntiles": (_I, [_I]),
     "aoc_pack": (C.c_int, [_I, _I, _I, _P, _P, _P]),
     "aoc_unpack": (C.c_int, [_I, _I, _I, _P, _P, _P]),
+    "aoc_pack_f32": (C.c_int, [_I, _I, _I, _P, _P, _P]),
+    "aoc_unpack_f32": (C.c_int, [_I, _I, _I, _P, _P, _P]),
     "aoc_step_batch": (C.c_int, [_P, _I] + [_P] * 10),
     "aoc_cost_batch": (C.c_int, [_P, _I] + [_P] * 10),
-    "aoc_traj_cost": (C.c_int, [_P, _P, _P, _P]),
+    "aoc_traj_cost": (C.c_int, [_P, _P, _P, _P, _P]),
     "aoc_initial_trajectory": (C.c_int, [_P, _D, _D, _P, _P, _P]),
     "aoc_rollout_cost": (C.c_int, [_P] * 9),
-    "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
-    "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 11),
+    "aoc_backward": (C.c_int, [_P, _I] + [_P] * 7),
+    "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 9),
     "aoc_linesearch_scratch_bytes": (_Z, [_I]),
     "aoc_linesearch": (C.c_int, [_P, _P, _I] + [_P] * 13),
-    "aoc_lqr_tracking": (C.c_int, [_P] * 8),
+    "aoc_lqr_tracking": (C.c_int, [_P] * 9),
     "aoc_ltv_lqr": (C.c_int, [_I, _I, _I] + [_P] * 17),
     "aoc_workspace_bytes": (_Z, [_I, _I]),
     "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 12),

@@ -66,9 +66,10 @@ class BatchProblem:
         ref = np.concatenate([xx_ref, uu_ref], axis=0).T.copy()  # [T][8]
         self.ref = torch.from_numpy(ref).to(self.device)
 
-    def c_problem(self, B, stream=None):
+    def c_problem(self, B, stream=None, x_in_f32=0, x_out_f32=0):
         torch = _torch()
         p = Problem()
+        p.x_in_f32, p.x_out_f32 = int(x_in_f32), int(x_out_f32)
         p.model = self.model
         p.QQt[:] = self.QQt.ravel().tolist()
         p.RRt[:] = self.RRt.ravel().tolist()
@@ -84,33 +85,39 @@ def ntiles(B):
     return (B + TILE - 1) // TILE
 
 
-def alloc_tiled(B, T, Cc, device, zero=False):
+def alloc_tiled(B, T, Cc, device, zero=False, f32=False):
     torch = _torch()
     shape = (ntiles(B), T, Cc, TILE)
-    return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float64, device=device)
+    return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32 if f32 else torch.float64, device=device)
 
 
-def pack(a_bct, device=None):
-    """(B,C,T) -> tiled [ntiles][T][C][64] on the device (aoc_pack)."""
+def pack(a_bct, device=None, f32=False):
+    """(B,C,T) fp64 -> tiled [ntiles][T][C][64] on the device (aoc_pack / aoc_pack_f32)."""
     torch = _torch()
     if device is None:
         device = a_bct.device if isinstance(a_bct, torch.Tensor) and a_bct.is_cuda else "cuda:0"
     src = _dev_f64(a_bct, device)
     B, Cc, T = src.shape
-    dst = alloc_tiled(B, T, Cc, src.device)
-    check(lib().aoc_pack(B, T, Cc, _ptr(src), _ptr(dst), C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)),
-          "aoc_pack")
+    dst = alloc_tiled(B, T, Cc, src.device, f32=f32)
+    fn = lib().aoc_pack_f32 if f32 else lib().aoc_pack
+    check(fn(B, T, Cc, _ptr(src), _ptr(dst), C.c_void_p(torch.cuda.current_stream(src.device).cuda_stream)), "aoc_pack")
     return dst
 
 
 def unpack(tiled, B):
-    """tiled -> (B,C,T) torch tensor on the device (aoc_unpack)."""
+    """tiled (fp64 or float32) -> (B,C,T) fp64 torch tensor on the device (aoc_unpack / aoc_unpack_f32)."""
     torch = _torch()
     nt, T, Cc, _ = tiled.shape
     dst = torch.empty((B, Cc, T), dtype=torch.float64, device=tiled.device)
-    check(lib().aoc_unpack(B, T, Cc, _ptr(tiled), _ptr(dst),
-                           C.c_void_p(torch.cuda.current_stream(tiled.device).cuda_stream)), "aoc_unpack")
+    fn = lib().aoc_unpack_f32 if tiled.dtype == torch.float32 else lib().aoc_unpack
+    check(fn(B, T, Cc, _ptr(tiled), _ptr(dst), C.c_void_p(torch.cuda.current_stream(tiled.device).cuda_stream)),
+          "aoc_unpack")
     return dst
+
+
+def unpack_vec(v, B):
+    """[ntiles][C][64] -> (B,C)"""
+    return v.permute(0, 2, 1).reshape(-1, v.shape[1])[:B]
 
 
 def pack_vec(a_bc, device):
@@ -167,9 +174,12 @@ def cost_batch(problem, x, u, xr, ur):
 class NewtonBatchSolver:
     """B independent NewtonMethod.optimize instances (reference optcon.py:341-529) on one GPU.
 
-    Device state (all tiled, fp64): three (x,u) iterate buffers in rotation, K~/g/du workspace,
-    per-trajectory scalars.  `iterate(kk)` = one outer iteration for every trajectory;
-    `solve()` adds the reference's termination and return-index behaviour per trajectory."""
+    Device state (tiled): three (x,u) iterate buffers in rotation — states as float32 (lossless: every
+    propagated state of the reference is a float32 value, aircraft_simplified.py:300; sample 0 lives in
+    the fp64 x0 array), inputs as fp64 — the K~/g/du workspace and per-trajectory scalars.  A
+    caller-supplied initial iterate whose samples are not float32 values is kept in an extra fp64
+    buffer and read from there by the first iteration.  `iterate(kk)` = one outer iteration for every
+    trajectory; `solve()` adds the reference's termination and return-index behaviour per trajectory."""
 
     def __init__(self, problem, B, params=None):
         torch = _torch()
@@ -178,8 +188,12 @@ class NewtonBatchSolver:
         dev = problem.device
         self.nt = ntiles(self.B)
         self.Bp = self.nt * TILE
-        self.xb = [alloc_tiled(B, self.T, 6, dev, zero=True) for _ in range(3)]
+        self.xb = [alloc_tiled(B, self.T, 6, dev, zero=True, f32=True) for _ in range(3)]
         self.ub = [alloc_tiled(B, self.T, 2, dev, zero=True) for _ in range(3)]
+        self.x64 = None            # fp64 copy of a caller-supplied initial iterate (only if needed)
+        self.cur_is64 = False      # the current iterate is the one in self.x64
+        self.x_init = None         # (B,6,T) fp64: what set_initial() was given (returned verbatim if a
+        self.u_init = None         #  trajectory stops at kk = 1, optcon.py:500-504)
         self.ws = torch.empty((lib().aoc_workspace_bytes(self.B, self.T) + 7) // 8, dtype=torch.float64, device=dev)
         f = lambda: torch.zeros(self.Bp, dtype=torch.float64, device=dev)
         self.J = [f(), f()]
@@ -192,9 +206,13 @@ class NewtonBatchSolver:
         self.kk = 0       # outer-iteration index of the current iterate
         self.jcur = 0
 
-    # -- problem struct with the current stream
-    def _p(self):
-        return self.problem.c_problem(self.B)
+    # -- problem struct with the current stream and the element types of this call's state arrays
+    def _p(self, x_in_f32=1, x_out_f32=1):
+        return self.problem.c_problem(self.B, x_in_f32=x_in_f32, x_out_f32=x_out_f32)
+
+    def _xin(self):
+        """(pointer, is_f32) of the current iterate's state array"""
+        return (self.x64, 0) if self.cur_is64 else (self.xb[self.cur], 1)
 
     def set_initial(self, xx_init, uu_init):
         """xx[:,:,0], uu[:,:,0] = xx_init, uu_init; x0 = xx_init[:,0] (reference optcon.py:395-398)."""
@@ -203,40 +221,51 @@ class NewtonBatchSolver:
         xi, ui = _dev_f64(xx_init, dev), _dev_f64(uu_init, dev)
         if tuple(xi.shape) != (self.B, 6, self.T) or tuple(ui.shape) != (self.B, 2, self.T):
             raise ValueError("xx_init must be (B,6,T)=(%d,6,%d) and uu_init (B,2,T)" % (self.B, self.T))
+        self.x_init, self.u_init = xi, ui
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        check(lib().aoc_pack(self.B, self.T, 6, _ptr(xi), _ptr(self.xb[0]), st), "aoc_pack")
+        self.x0.copy_(pack_vec(xi[:, :, 0], dev))
+        tail = xi[:, :, 1:]
+        self.cur_is64 = not bool(torch.equal(tail.to(torch.float32).to(torch.float64), tail))
+        if self.cur_is64:
+            if self.x64 is None:
+                self.x64 = alloc_tiled(self.B, self.T, 6, dev)
+            check(lib().aoc_pack(self.B, self.T, 6, _ptr(xi), _ptr(self.x64), st), "aoc_pack")
+        check(lib().aoc_pack_f32(self.B, self.T, 6, _ptr(xi), _ptr(self.xb[0]), st), "aoc_pack_f32")
         check(lib().aoc_pack(self.B, self.T, 2, _ptr(ui), _ptr(self.ub[0]), st), "aoc_pack")
-        self.x0.copy_(self.xb[0][:, 0, :, :])
         self.cur, self.kk, self.jcur = 0, 0, 0
         self.status.zero_()
-        p = self._p()
-        check(lib().aoc_traj_cost(C.byref(p), _ptr(self.xb[0]), _ptr(self.ub[0]), _ptr(self.J[0])), "aoc_traj_cost")
+        x, f32 = self._xin()
+        p = self._p(f32)
+        check(lib().aoc_traj_cost(C.byref(p), _ptr(x), _ptr(self.ub[0]), _ptr(self.x0), _ptr(self.J[0])), "aoc_traj_cost")
 
     def set_initial_from_x0(self, x0, kp=5.0, kt=2.5):
         """Initial guess by the reference's P-controller law (aircraft_simplified.py:134-147) rolled out
         on the device from x0 (B,6), straight into the iterate buffers."""
-        torch = _torch()
         dev = self.problem.device
         self.x0.copy_(pack_vec(x0, dev))
+        self.x_init = self.u_init = None
+        self.cur_is64 = False
         p = self._p()
         check(lib().aoc_initial_trajectory(C.byref(p), float(kp), float(kt), _ptr(self.x0), _ptr(self.xb[0]),
                                            _ptr(self.ub[0])), "aoc_initial_trajectory")
         self.cur, self.kk, self.jcur = 0, 0, 0
         self.status.zero_()
-        check(lib().aoc_traj_cost(C.byref(p), _ptr(self.xb[0]), _ptr(self.ub[0]), _ptr(self.J[0])), "aoc_traj_cost")
+        check(lib().aoc_traj_cost(C.byref(p), _ptr(self.xb[0]), _ptr(self.ub[0]), _ptr(self.x0), _ptr(self.J[0])),
+              "aoc_traj_cost")
 
     def iterate(self, kk=None):
         """One outer iteration (steps A-G of SURVEY 3.2) for every trajectory; asynchronous."""
         if kk is None:
             kk = self.kk
-        p = self._p()
+        x, f32 = self._xin()
+        p = self._p(f32)
         c, n = self.cur, (self.cur + 1) % 3
         jc, jn = self.jcur, 1 - self.jcur
-        check(lib().aoc_newton_iterate(C.byref(p), C.byref(self.params), int(kk), _ptr(self.xb[c]), _ptr(self.ub[c]),
+        check(lib().aoc_newton_iterate(C.byref(p), C.byref(self.params), int(kk), _ptr(x), _ptr(self.ub[c]),
                                        _ptr(self.x0), _ptr(self.J[jc]), _ptr(self.ws), _ptr(self.xb[n]),
                                        _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.descent), _ptr(self.stepsize),
                                        _ptr(self.ntrials), _ptr(self.status)), "aoc_newton_iterate")
-        self.cur, self.jcur, self.kk = n, jn, kk + 1
+        self.cur, self.jcur, self.kk, self.cur_is64 = n, jn, kk + 1, False
 
     def iterate_timed(self, kk=None):
         """Same launches as iterate(), issued pass by pass with HIP events recorded on the launch
@@ -245,39 +274,49 @@ class NewtonBatchSolver:
         torch = _torch()
         if kk is None:
             kk = self.kk
-        p = self._p()
+        x, f32 = self._xin()
+        p = self._p(f32)
         prm = self.params
         c, n = self.cur, (self.cur + 1) % 3
         jc, jn = self.jcur, 1 - self.jcur
         nel14 = lib().aoc_tiled_elems(self.B, self.T, 14)
         nel2 = lib().aoc_tiled_elems(self.B, self.T, 2)
         Kt, g, du = self.ws[:nel14], self.ws[nel14:nel14 + nel2], self.ws[nel14 + nel2:nel14 + 2 * nel2]
-        st = torch.cuda.current_stream(self.problem.device)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        ev[0].record(st)
-        check(lib().aoc_backward(C.byref(p), int(kk > prm.hessian_switch), _ptr(self.xb[c]), _ptr(self.ub[c]),
-                                 _ptr(Kt), _ptr(g), None, _ptr(self.status)), "aoc_backward")
-        ev[1].record(st)
         nsp = self.n_spec
         Jt = self.ws[nel14 + 2 * nel2:nel14 + 2 * nel2 + 3 * self.Bp]
         scratch = self.ws[nel14 + 2 * nel2 + 3 * self.Bp:]
-        check(lib().aoc_forward(C.byref(p), C.byref(prm), nsp, _ptr(self.xb[c]), _ptr(self.ub[c]), _ptr(self.x0),
-                                _ptr(Kt), _ptr(g), _ptr(du), _ptr(self.descent), None, None,
-                                _ptr(Jt), _ptr(self.status)), "aoc_forward")
+        st = torch.cuda.current_stream(self.problem.device)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record(st)
+        check(lib().aoc_backward(C.byref(p), int(kk > prm.hessian_switch), _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
+                                 _ptr(Kt), _ptr(g), None, _ptr(self.status)), "aoc_backward")
+        ev[1].record(st)
+        check(lib().aoc_forward(C.byref(p), C.byref(prm), nsp, _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
+                                _ptr(Kt), _ptr(g), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status)),
+              "aoc_forward")
         ev[2].record(st)
         check(lib().aoc_linesearch(C.byref(p), C.byref(prm), nsp, _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
                                    _ptr(self.J[jc]), _ptr(self.descent), _ptr(Jt), _ptr(self.xb[n]),
                                    _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.stepsize), _ptr(self.ntrials),
                                    _ptr(self.status), _ptr(scratch)), "aoc_linesearch")
         ev[3].record(st)
-        self.cur, self.jcur, self.kk = n, jn, kk + 1
+        self.cur, self.jcur, self.kk, self.cur_is64 = n, jn, kk + 1, False
         return ev
 
     # -- results ---------------------------------------------------------------------------------
-    def current(self, which=0):
-        """Current iterate (which=0), previous (-1) or the one before (-2) as numpy (B,6,T),(B,2,T)."""
-        i = (self.cur + which) % 3
-        return unpack(self.xb[i], self.B).cpu().numpy(), unpack(self.ub[i], self.B).cpu().numpy()
+    def _unpack_iterate(self, i):
+        """(B,6,T), (B,2,T) fp64 device tensors of buffer i, sample 0 restored from the fp64 x0."""
+        if self.cur_is64 and i == self.cur:
+            xx = unpack(self.x64, self.B)
+        else:
+            xx = unpack(self.xb[i], self.B)
+            xx[:, :, 0] = unpack_vec(self.x0, self.B)
+        return xx, unpack(self.ub[i], self.B)
+
+    def current(self):
+        """Current iterate as numpy (B,6,T), (B,2,T)."""
+        xx, uu = self._unpack_iterate(self.cur)
+        return xx.cpu().numpy(), uu.cpu().numpy()
 
     def scalars(self):
         """Per-trajectory scalars of the LAST iteration: cost of the iterate it started from, descent,
@@ -309,6 +348,7 @@ class NewtonBatchSolver:
         dev = self.problem.device
         active = torch.ones(self.Bp, dtype=torch.bool, device=dev)
         iters = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
+        ret = torch.full((self.Bp,), -2, dtype=torch.int32, device=dev)  # returned history index (-2: not yet)
         res_x = torch.zeros_like(self.xb[0])
         res_u = torch.zeros_like(self.ub[0])
         hist = dict(cost=[], descent=[], stepsize=[], ntrials=[])
@@ -327,6 +367,7 @@ class NewtonBatchSolver:
                     res_x = torch.where(m, self.xb[(self.cur + 1) % 3], res_x)
                     res_u = torch.where(m, self.ub[(self.cur + 1) % 3], res_u)
                 # kk == 0: xx[:,:,-1] is the untouched, all-zero last history slot
+                ret = torch.where(conv, torch.full_like(ret, kk - 1), ret)
                 self.status |= conv.to(torch.int32) * _lib.ST_CONVERGED
                 active = active & ~conv
             if callback is not None:
@@ -341,8 +382,16 @@ class NewtonBatchSolver:
         m = active.reshape(self.nt, 1, 1, TILE)
         res_x = torch.where(m, self.xb[self.cur], res_x)
         res_u = torch.where(m, self.ub[self.cur], res_u)
+        ret = torch.where(active, torch.full_like(ret, last + 1), ret)
         xs = unpack(res_x, B)
         us = unpack(res_u, B)
+        retB = ret[:B]
+        real = retB >= 0
+        xs[:, :, 0] = torch.where(real[:, None], unpack_vec(self.x0, B), xs[:, :, 0])  # sample 0 is the fp64 x0
+        if self.x_init is not None:  # index 0 is the caller's initial iterate, verbatim
+            is0 = retB == 0
+            xs = torch.where(is0[:, None, None], self.x_init, xs)
+            us = torch.where(is0[:, None, None], self.u_init, us)
         us[:, :, -1] = us[:, :, -2]  # optcon.py:505
         return dict(xx_star=xs.cpu().numpy(), uu_star=us.cpu().numpy(), iters=iters[:B].cpu().numpy(),
                     converged=(~active[:B]).cpu().numpy(), status=self.status[:B].cpu().numpy(),
@@ -356,17 +405,20 @@ class NewtonBatchSolver:
 def traj_cost(problem, xx, uu):
     """Cost of stored trajectories (reference optcon.py:417-424).  xx (B,6,T), uu (B,2,T) -> (B,)"""
     torch = _torch()
+    xx = np.asarray(xx, dtype=np.float64)
     xt, ut = pack(xx, problem.device), pack(uu, problem.device)
     B = xx.shape[0]
+    x0t = pack_vec(xx[:, :, 0], problem.device)
     J = torch.empty(ntiles(B) * TILE, dtype=torch.float64, device=problem.device)
     p = problem.c_problem(B)
-    check(lib().aoc_traj_cost(C.byref(p), _ptr(xt), _ptr(ut), _ptr(J)), "aoc_traj_cost")
+    check(lib().aoc_traj_cost(C.byref(p), _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(J)), "aoc_traj_cost")
     return J[:B].cpu().numpy()
 
 
-def rollout_cost(problem, x0, uu, du=None, alpha=None, write=True):
+def rollout_cost(problem, x0, uu, du=None, alpha=None, write=True, f32=False):
     """get_update + trial cost (reference optcon.py:176-200, :250-264).
-    x0 (B,6), uu (B,2,T), du (B,2,T) or None, alpha (B,) -> (xx (B,6,T), uu' (B,2,T), J (B,), status)"""
+    x0 (B,6), uu (B,2,T), du (B,2,T) or None, alpha (B,) -> (xx (B,6,T), uu' (B,2,T), J (B,), status).
+    f32: store the state trajectory as float32 on the device (same values)."""
     torch = _torch()
     dev = problem.device
     B = uu.shape[0]
@@ -378,47 +430,49 @@ def rollout_cost(problem, x0, uu, du=None, alpha=None, write=True):
     if du is not None:
         al = torch.zeros(nt * TILE, dtype=torch.float64, device=dev)
         al[:B] = _dev_f64(np.broadcast_to(np.asarray(alpha, dtype=np.float64), (B,)).copy(), dev)
-    xo = alloc_tiled(B, problem.T, 6, dev) if write else None
+    xo = alloc_tiled(B, problem.T, 6, dev, f32=f32) if write else None
     uo = alloc_tiled(B, problem.T, 2, dev) if write else None
     J = torch.empty(nt * TILE, dtype=torch.float64, device=dev)
     st = torch.zeros(nt * TILE, dtype=torch.int32, device=dev)
-    p = problem.c_problem(B)
+    p = problem.c_problem(B, x_out_f32=int(f32))
     check(lib().aoc_rollout_cost(C.byref(p), _ptr(x0t), _ptr(ut), _ptr(dt_), _ptr(al), _ptr(xo), _ptr(uo), _ptr(J),
                                  _ptr(st)), "aoc_rollout_cost")
-    xx = unpack(xo, B).cpu().numpy() if write else None
-    un = unpack(uo, B).cpu().numpy() if write else None
+    xx = un = None
+    if write:
+        xd = unpack(xo, B)
+        xd[:, :, 0] = _dev_f64(x0, dev)
+        xx, un = xd.cpu().numpy(), unpack(uo, B).cpu().numpy()
     return xx, un, J[:B].cpu().numpy(), st[:B].cpu().numpy()
 
 
-def backward_forward(problem, xx, uu, full_hessian, stepsize_0=1.0):
+def backward_forward(problem, xx, uu, full_hessian, stepsize_0=1.0, f32=False):
     """One backward + forward pass (reference optcon.py:429-477 and the first Armijo trial).
-    Returns dict with K~ (B,2,7,T), g (B,2,T), du (B,2,T), descent (B,), lmbd0 (B,6),
-    xx_new, uu_new, J_new, status."""
+    Returns dict with K~ (B,2,7,T), g (B,2,T), du (B,2,T), descent (B,), lmbd0 (B,6), J_trial0, status.
+    f32: hand the state trajectory over as float32 (requires float32-valued samples t >= 1)."""
     torch = _torch()
     dev = problem.device
+    xx = np.asarray(xx, dtype=np.float64)
     B, T = xx.shape[0], problem.T
     nt = ntiles(B)
-    xt, ut = pack(xx, dev), pack(uu, dev)
+    xt, ut = pack(xx, dev, f32=f32), pack(uu, dev)
     Kt = alloc_tiled(B, T, 14, dev, zero=True)
     g = alloc_tiled(B, T, 2, dev, zero=True)
     du = alloc_tiled(B, T, 2, dev)
-    xn, un = alloc_tiled(B, T, 6, dev), alloc_tiled(B, T, 2, dev)
     lm0 = torch.empty((nt, 6, TILE), dtype=torch.float64, device=dev)
     desc = torch.empty(nt * TILE, dtype=torch.float64, device=dev)
     Jn = torch.empty(nt * TILE, dtype=torch.float64, device=dev)
     st = torch.zeros(nt * TILE, dtype=torch.int32, device=dev)
-    x0t = xt[:, 0, :, :].contiguous()
-    p = problem.c_problem(B)
-    check(lib().aoc_backward(C.byref(p), int(bool(full_hessian)), _ptr(xt), _ptr(ut), _ptr(Kt), _ptr(g), _ptr(lm0),
-                             _ptr(st)), "aoc_backward")
+    x0t = pack_vec(xx[:, :, 0], dev)
+    p = problem.c_problem(B, x_in_f32=int(f32))
+    check(lib().aoc_backward(C.byref(p), int(bool(full_hessian)), _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(g),
+                             _ptr(lm0), _ptr(st)), "aoc_backward")
     prm = make_params(stepsize_0=stepsize_0)
     check(lib().aoc_forward(C.byref(p), C.byref(prm), 1, _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(g), _ptr(du),
-                            _ptr(desc), _ptr(xn), _ptr(un), _ptr(Jn), _ptr(st)), "aoc_forward")
+                            _ptr(desc), _ptr(Jn), _ptr(st)), "aoc_forward")
     KK = unpack(Kt, B).cpu().numpy().reshape(B, 2, 7, T)
     return dict(KK=KK, g=unpack(g, B).cpu().numpy(), du=unpack(du, B).cpu().numpy(),
-                descent=desc[:B].cpu().numpy(), lmbd0=lm0.permute(0, 2, 1).reshape(-1, 6)[:B].cpu().numpy(),
-                xx_new=unpack(xn, B).cpu().numpy(), uu_new=unpack(un, B).cpu().numpy(),
-                J_new=Jn[:B].cpu().numpy(), status=st[:B].cpu().numpy())
+                descent=desc[:B].cpu().numpy(), lmbd0=unpack_vec(lm0, B).cpu().numpy(),
+                J_trial0=Jn[:B].cpu().numpy(), status=st[:B].cpu().numpy())
 
 
 def lqr_tracking_batch(problem, xx_opt, uu_opt, delta):
@@ -433,12 +487,13 @@ def lqr_tracking_batch(problem, xx_opt, uu_opt, delta):
     xt, ut = pack(xx_opt, dev), pack(uu_opt, dev)
     x0r = xx_opt[:, :, 0] + np.broadcast_to(np.asarray(delta, dtype=np.float64), (B, 6))  # lqr_tracking.py:265
     x0t = pack_vec(x0r, dev)
+    xo0 = pack_vec(xx_opt[:, :, 0], dev)
     Kg = alloc_tiled(B, T, 12, dev)
     xr, ur = alloc_tiled(B, T, 6, dev), alloc_tiled(B, T, 2, dev)
     st = torch.zeros(nt * TILE, dtype=torch.int32, device=dev)
     p = problem.c_problem(B)
-    check(lib().aoc_lqr_tracking(C.byref(p), _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kg), _ptr(xr), _ptr(ur), _ptr(st)),
-          "aoc_lqr_tracking")
+    check(lib().aoc_lqr_tracking(C.byref(p), _ptr(xt), _ptr(ut), _ptr(xo0), _ptr(x0t), _ptr(Kg), _ptr(xr), _ptr(ur),
+                                 _ptr(st)), "aoc_lqr_tracking")
     KK = unpack(Kg, B).cpu().numpy().reshape(B, 2, 6, T)
     return unpack(xr, B).cpu().numpy(), unpack(ur, B).cpu().numpy(), KK, st[:B].cpu().numpy()
 

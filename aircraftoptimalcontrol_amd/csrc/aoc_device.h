@@ -297,30 +297,7 @@ struct StageFlags { bool singular, regularised; };
 __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, double P[21], double p[6],
                                                 const double Qs[21], double s02, double s03, double s05,
                                                 const double hq[6], const double hr[2], double Kt[14]) {
-    // W = P A  (6x6, full)
-    double W[6][6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const double pi0 = SYM(P, i, 0), pi1 = SYM(P, i, 1), pi2 = SYM(P, i, 2), pi3 = SYM(P, i, 3),
-                     pi4 = SYM(P, i, 4), pi5 = SYM(P, i, 5);
-        W[i][0] = pi0;
-        W[i][1] = pi1;
-        W[i][2] = pi0 * l.a02 + pi1 * l.a12 + pi2 * l.a22 + pi5 * l.a52;
-        W[i][3] = pi2 * l.a23 + pi3 + pi5 * l.a53;
-        W[i][4] = pi3 * k.dt + pi4;
-        W[i][5] = pi0 * l.a05 + pi1 * l.a15 + pi2 * l.a25 + pi5 * l.a55;
-    }
-    // G = B^T W + S (2x6), h = B^T p + r/2
-    double G0[6], G1[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-        G0[j] = l.b20 * W[2][j] + l.b50 * W[5][j];
-        G1[j] = k.b41 * W[4][j];
-    }
-    G0[2] += s02; G0[3] += s03; G0[5] += s05;
-    const double h0 = l.b20 * p[2] + l.b50 * p[5] + hr[0];
-    const double h1 = k.b41 * p[4] + hr[1];
-    // M = R + B^T P B
+    // M = R + B^T P B  (2x2, symmetric), from the six entries of P that B touches
     const double P22 = P[sidx(2, 2)], P24 = P[sidx(2, 4)], P25 = P[sidx(2, 5)], P44 = P[sidx(4, 4)],
                  P45 = P[sidx(4, 5)], P55 = P[sidx(5, 5)];
     const double bp2 = l.b20 * P22 + l.b50 * P25;   // (B^T P)[0,2]
@@ -334,22 +311,49 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, d
     fl.singular = (det == 0.0);
     const double idet = 1.0 / det;
     const double i00 = M11 * idet, i01 = -M01 * idet, i11 = M00 * idet;
-    // MiG = M^-1 [h, G]
-    const double mh0 = i00 * h0 + i01 * h1, mh1 = i01 * h0 + i11 * h1;
-    double MG0[6], MG1[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-        MG0[j] = i00 * G0[j] + i01 * G1[j];
-        MG1[j] = i01 * G0[j] + i11 * G1[j];
-    }
-    // gains; M positive definite <=> tr > 0 and det > 0 (equivalent to all(eigvals(M) > 0), :745)
+    // M positive definite <=> tr > 0 and det > 0 (equivalent to all(eigvals(M) > 0), optcon.py:745)
     const bool pd = (M00 + M11 > 0.0) && (det > 0.0);
     fl.regularised = !pd;
-    if (pd) {
-        Kt[0] = -mh0; Kt[7] = -mh1;
+    // affine column: h = B^T p + r/2, M^-1 h
+    const double h0 = l.b20 * p[2] + l.b50 * p[5] + hr[0];
+    const double h1 = k.b41 * p[4] + hr[1];
+    const double mh0 = i00 * h0 + i01 * h1, mh1 = i01 * h0 + i11 * h1;
+    Kt[0] = -mh0; Kt[7] = -mh1;
+    // Column by column: W[:,j] = (P A)[:,j], G[:,j] = (B^T W)[:,j] + S[:,j], M^-1 G[:,j],
+    // z = (A^T W)[:,j], P_t[i,j] = Q[i,j] + z[i] - G[:,i]^T M^-1 G[:,j] for i <= j.  Only one column of W
+    // is alive at a time; the new P is built beside the old one.
+    double Pn[21], G0[6], G1[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) { Kt[1 + j] = -MG0[j]; Kt[8 + j] = -MG1[j]; }
-    } else {
+    for (int j = 0; j < 6; j++) {
+        double w[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const double pi0 = SYM(P, i, 0), pi1 = SYM(P, i, 1), pi2 = SYM(P, i, 2), pi3 = SYM(P, i, 3),
+                         pi4 = SYM(P, i, 4), pi5 = SYM(P, i, 5);
+            w[i] = j == 0 ? pi0
+                 : j == 1 ? pi1
+                 : j == 2 ? pi0 * l.a02 + pi1 * l.a12 + pi2 * l.a22 + pi5 * l.a52
+                 : j == 3 ? pi2 * l.a23 + pi3 + pi5 * l.a53
+                 : j == 4 ? pi3 * k.dt + pi4
+                          : pi0 * l.a05 + pi1 * l.a15 + pi2 * l.a25 + pi5 * l.a55;
+        }
+        double g0 = l.b20 * w[2] + l.b50 * w[5];
+        const double g1 = k.b41 * w[4];
+        if (j == 2) g0 += s02;
+        if (j == 3) g0 += s03;
+        if (j == 5) g0 += s05;
+        G0[j] = g0; G1[j] = g1;
+        const double mg0 = i00 * g0 + i01 * g1, mg1 = i01 * g0 + i11 * g1;
+        Kt[1 + j] = -mg0; Kt[8 + j] = -mg1;
+        const double z[6] = {w[0], w[1],
+                             l.a02 * w[0] + l.a12 * w[1] + l.a22 * w[2] + l.a52 * w[5],
+                             l.a23 * w[2] + w[3] + l.a53 * w[5],
+                             k.dt * w[3] + w[4],
+                             l.a05 * w[0] + l.a15 * w[1] + l.a25 * w[2] + l.a55 * w[5]};
+#pragma unroll
+        for (int i = 0; i <= j; i++) Pn[sidx(i, j)] = Qs[sidx(i, j)] + z[i] - (G0[i] * mg0 + G1[i] * mg1);
+    }
+    if (!pd) {  // gains from the regularised M + 0.5 I (optcon.py:745-751); the Riccati update above keeps M (Q3)
         const double r00 = M00 + 0.5, r11 = M11 + 0.5;
         const double rdet = r00 * r11 - M01 * M01;
         if (rdet == 0.0) fl.singular = true;
@@ -367,19 +371,8 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, d
     At_vec(k, l, p, ap);
 #pragma unroll
     for (int i = 0; i < 6; i++) p[i] = hq[i] + ap[i] - (G0[i] * mh0 + G1[i] * mh1);
-    // P_t = Q + A^T W - G^T (M^-1 G), upper triangle
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-        const double z0 = W[0][j], z1 = W[1][j];
-        const double z2 = l.a02 * W[0][j] + l.a12 * W[1][j] + l.a22 * W[2][j] + l.a52 * W[5][j];
-        const double z3 = l.a23 * W[2][j] + W[3][j] + l.a53 * W[5][j];
-        const double z4 = k.dt * W[3][j] + W[4][j];
-        const double z5 = l.a05 * W[0][j] + l.a15 * W[1][j] + l.a25 * W[2][j] + l.a55 * W[5][j];
-        const double z[6] = {z0, z1, z2, z3, z4, z5};
-#pragma unroll
-        for (int i = 0; i <= j; i++)
-            P[sidx(i, j)] = Qs[sidx(i, j)] + z[i] - (G0[i] * MG0[j] + G1[i] * MG1[j]);
-    }
+    for (int e = 0; e < 21; e++) P[e] = Pn[e];
     return fl;
 }
 

@@ -17,26 +17,55 @@
 
 using namespace aoc;
 
+// State trajectories (tiled, 6 components) are stored either as fp64 or as float32.  Every
+// propagated state of the reference is a float32 value (aircraft_simplified.py:300), so float32
+// storage is lossless for samples t >= 1 and halves their HBM traffic; sample 0 is x0, an arbitrary
+// fp64 value, and is always read from the separate fp64 x0 array ([ntiles][6][64]).
+template <typename XT>
+__device__ __forceinline__ void load_state(const XT* __restrict__ x, const double* __restrict__ x0, int tile, int T,
+                                           int t, int lane, double xs[6]) {
+    if (t == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 6; c++) xs[c] = (double)x[tix<6>(tile, T, t, c, lane)];
+    }
+}
+
+#define AOC_DISPATCH_BOOL(flag, NAME, ...)            \
+    do {                                              \
+        if (flag) { constexpr bool NAME = true; __VA_ARGS__; } \
+        else { constexpr bool NAME = false; __VA_ARGS__; }      \
+    } while (0)
+#define AOC_DISPATCH_XT(f32, NAME, ...)               \
+    do {                                              \
+        if (f32) { using NAME = float; __VA_ARGS__; } \
+        else { using NAME = double; __VA_ARGS__; }    \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------
 // layout conversion
 // ---------------------------------------------------------------------------------------------
-__global__ void k_pack(int B, int T, int C, const double* __restrict__ src, double* __restrict__ dst) {
+template <typename ET>
+__global__ void k_pack(int B, int T, int C, const double* __restrict__ src, ET* __restrict__ dst) {
     // one block per (tile, chunk of t); threads: lane fastest on the write side
     const int tile = blockIdx.x, lane = threadIdx.x;
     int b = tile * TILE + lane;
     if (b >= B) b = B - 1;
     for (int t = blockIdx.y; t < T; t += gridDim.y)
         for (int c = 0; c < C; c++)
-            dst[(((size_t)tile * T + t) * C + c) * TILE + lane] = src[((size_t)b * C + c) * T + t];
+            dst[(((size_t)tile * T + t) * C + c) * TILE + lane] = (ET)src[((size_t)b * C + c) * T + t];
 }
 
-__global__ void k_unpack(int B, int T, int C, const double* __restrict__ src, double* __restrict__ dst) {
+template <typename ET>
+__global__ void k_unpack(int B, int T, int C, const ET* __restrict__ src, double* __restrict__ dst) {
     const int tile = blockIdx.x, lane = threadIdx.x;
     const int b = tile * TILE + lane;
     if (b >= B) return;
     for (int t = blockIdx.y; t < T; t += gridDim.y)
         for (int c = 0; c < C; c++)
-            dst[((size_t)b * C + c) * T + t] = src[(((size_t)tile * T + t) * C + c) * TILE + lane];
+            dst[((size_t)b * C + c) * T + t] = (double)src[(((size_t)tile * T + t) * C + c) * TILE + lane];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -113,20 +142,18 @@ __global__ void k_cost_batch(KConst k, int n, const double* __restrict__ x, cons
 // ---------------------------------------------------------------------------------------------
 
 // cost of a stored trajectory, t ascending then terminal (optcon.py:417-424)
-template <bool DIAG>
+template <bool DIAG, typename XT>
 __global__ __launch_bounds__(TILE) void k_traj_cost(KConst k, const double* __restrict__ ref,
-                                                    const double* __restrict__ x, const double* __restrict__ u,
-                                                    double* __restrict__ J) {
+                                                    const XT* __restrict__ x, const double* __restrict__ u,
+                                                    const double* __restrict__ x0, double* __restrict__ J) {
     const int tile = blockIdx.x, lane = threadIdx.x, T = k.T;
     double JJ = 0.0, xs[6], q[6], r[2];
     for (int t = 0; t < T - 1; t++) {
-#pragma unroll
-        for (int c = 0; c < 6; c++) xs[c] = x[tix<6>(tile, T, t, c, lane)];
+        load_state(x, x0, tile, T, t, lane, xs);
         const double u0 = u[tix<2>(tile, T, t, 0, lane)], u1 = u[tix<2>(tile, T, t, 1, lane)];
         JJ += stage_cost<DIAG>(k, xs, u0, u1, ref + (size_t)t * 8, q, r);
     }
-#pragma unroll
-    for (int c = 0; c < 6; c++) xs[c] = x[tix<6>(tile, T, T - 1, c, lane)];
+    load_state(x, x0, tile, T, T - 1, lane, xs);
     JJ += term_cost<DIAG>(k, xs, ref + (size_t)(T - 1) * 8, q);
     J[tile * TILE + lane] = JJ;
 }
@@ -137,11 +164,11 @@ __global__ __launch_bounds__(TILE) void k_traj_cost(KConst k, const double* __re
 // one wavefront is to run the (u, du) loads far ahead: a register ring of ROLL_PF stages.
 constexpr int ROLL_PF = 8;
 
-template <bool DIAG, bool WRITE>
+template <bool DIAG, bool WRITE, typename XO>
 __device__ __forceinline__ double rollout(const KConst& k, const double* __restrict__ ref, int tile, int lane,
                                           const double x0[6], const double* __restrict__ u,
                                           const double* __restrict__ du, double a, bool wmask,
-                                          double* __restrict__ x_out, double* __restrict__ u_out, int& flags) {
+                                          XO* __restrict__ x_out, double* __restrict__ u_out, int& flags) {
     const int T = k.T;
     double xs[6], xn[6], q[6], r[2];
     double JJ = 0.0;
@@ -149,7 +176,7 @@ __device__ __forceinline__ double rollout(const KConst& k, const double* __restr
     for (int c = 0; c < 6; c++) xs[c] = x0[c];
     if (WRITE && wmask) {
 #pragma unroll
-        for (int c = 0; c < 6; c++) x_out[tix<6>(tile, T, 0, c, lane)] = xs[c];
+        for (int c = 0; c < 6; c++) x_out[tix<6>(tile, T, 0, c, lane)] = (XO)xs[c];
     }
     double ub[ROLL_PF][2], db[ROLL_PF][2];
 #pragma unroll
@@ -189,7 +216,7 @@ __device__ __forceinline__ double rollout(const KConst& k, const double* __restr
                 u_out[tix<2>(tile, T, t, 0, lane)] = u0;
                 u_out[tix<2>(tile, T, t, 1, lane)] = u1;
 #pragma unroll
-                for (int c = 0; c < 6; c++) x_out[tix<6>(tile, T, t + 1, c, lane)] = xn[c];
+                for (int c = 0; c < 6; c++) x_out[tix<6>(tile, T, t + 1, c, lane)] = (XO)xn[c];
             }
 #pragma unroll
             for (int c = 0; c < 6; c++) xs[c] = xn[c];
@@ -203,11 +230,11 @@ __device__ __forceinline__ double rollout(const KConst& k, const double* __restr
     return JJ;
 }
 
-template <bool DIAG, bool WRITE>
+template <bool DIAG, bool WRITE, typename XO>
 __global__ __launch_bounds__(TILE) void k_rollout_cost(KConst k, const double* __restrict__ ref,
                                                        const double* __restrict__ x0, const double* __restrict__ u,
                                                        const double* __restrict__ du, const double* __restrict__ alpha,
-                                                       double* __restrict__ x_out, double* __restrict__ u_out,
+                                                       XO* __restrict__ x_out, double* __restrict__ u_out,
                                                        double* __restrict__ J_out, int* __restrict__ status) {
     const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane;
     double xs[6];
@@ -215,22 +242,23 @@ __global__ __launch_bounds__(TILE) void k_rollout_cost(KConst k, const double* _
     for (int c = 0; c < 6; c++) xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
     const double a = (du && alpha) ? alpha[b] : 0.0;
     int flags = 0;
-    const double JJ = rollout<DIAG, WRITE>(k, ref, tile, lane, xs, u, du, a, true, x_out, u_out, flags);
+    const double JJ = rollout<DIAG, WRITE, XO>(k, ref, tile, lane, xs, u, du, a, true, x_out, u_out, flags);
     if (JJ != JJ || JJ - JJ != 0.0) flags |= AOC_ST_NAN;
     J_out[b] = JJ;
     if (status && flags) status[b] |= flags;
 }
 
 // Dynamics.get_initial_trajectory (aircraft_simplified.py:126-148): P-controller rollout from x0.
+template <typename XO>
 __global__ __launch_bounds__(TILE) void k_initial_traj(KConst k, double kp, double kt, const double* __restrict__ ref,
-                                                       const double* __restrict__ x0, double* __restrict__ x_out,
+                                                       const double* __restrict__ x0, XO* __restrict__ x_out,
                                                        double* __restrict__ u_out) {
     const int tile = blockIdx.x, lane = threadIdx.x, T = k.T;
     double xs[6], xn[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) {
         xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
-        x_out[tix<6>(tile, T, 0, c, lane)] = xs[c];
+        x_out[tix<6>(tile, T, 0, c, lane)] = (XO)xs[c];
     }
     for (int i = 0; i < T - 1; i++) {
         const double* xr = ref + (size_t)(i + 1) * 8;
@@ -245,24 +273,27 @@ __global__ __launch_bounds__(TILE) void k_initial_traj(KConst k, double kp, doub
         u_out[tix<2>(tile, T, i, 0, lane)] = u0;
         u_out[tix<2>(tile, T, i, 1, lane)] = u1;
 #pragma unroll
-        for (int c = 0; c < 6; c++) { x_out[tix<6>(tile, T, i + 1, c, lane)] = xn[c]; xs[c] = xn[c]; }
+        for (int c = 0; c < 6; c++) { x_out[tix<6>(tile, T, i + 1, c, lane)] = (XO)xn[c]; xs[c] = xn[c]; }
     }
     u_out[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
     u_out[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
 }
 
 // Backward pass (see aoc_backward in include/aoc.h).
-template <bool DIAG, bool FULL>
+// The (x,u) loads of the next BW_PF stages are kept in flight in a register ring.
+constexpr int BW_PF = 1;
+
+template <bool DIAG, bool FULL, typename XT>
 __global__ __launch_bounds__(TILE) void k_backward(KConst k, const double* __restrict__ ref,
-                                                   const double* __restrict__ x, const double* __restrict__ u,
-                                                   double* __restrict__ Kt, double* __restrict__ g,
+                                                   const XT* __restrict__ x, const double* __restrict__ u,
+                                                   const double* __restrict__ x0, double* __restrict__ Kt,
+                                                   double* __restrict__ g,
                                                    double* __restrict__ lmbd0, int* __restrict__ status) {
     const int tile = blockIdx.x, lane = threadIdx.x, T = k.T;
     double P[21], p[6], lam[6], Qb[21], xs[6], q[6], r[2];
     int flags = 0;
     // terminal condition (optcon.py:429-432, :688-690, :716): P = Q_T, p = q_f/2, lambda = q_f
-#pragma unroll
-    for (int c = 0; c < 6; c++) xs[c] = x[tix<6>(tile, T, T - 1, c, lane)];
+    load_state(x, x0, tile, T, T - 1, lane, xs);
     term_cost<DIAG>(k, xs, ref + (size_t)(T - 1) * 8, q);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -274,20 +305,34 @@ __global__ __launch_bounds__(TILE) void k_backward(KConst k, const double* __res
             Qb[sidx(i, j)] = k.Q[i * 6 + j];
         }
     }
-    double xn[6], un0, un1;
+    XT xb[BW_PF][6];  // kept in storage precision: a float32 ring costs half the registers
+    double ubuf[BW_PF][2];
 #pragma unroll
-    for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, T - 2, c, lane)];
-    un0 = u[tix<2>(tile, T, T - 2, 0, lane)];
-    un1 = u[tix<2>(tile, T, T - 2, 1, lane)];
-    for (int t = T - 2; t >= 0; t--) {
+    for (int i = 0; i < BW_PF; i++) {
+        const int tp = T - 2 - i >= 0 ? T - 2 - i : 0;
 #pragma unroll
-        for (int c = 0; c < 6; c++) xs[c] = xn[c];
-        const double u0 = un0, u1 = un1;
-        if (t > 0) {  // prefetch stage t-1 while stage t computes
+        for (int c = 0; c < 6; c++) xb[i][c] = x[tix<6>(tile, T, tp, c, lane)];
+        ubuf[i][0] = u[tix<2>(tile, T, tp, 0, lane)];
+        ubuf[i][1] = u[tix<2>(tile, T, tp, 1, lane)];
+    }
+    for (int tb = T - 2; tb >= 0; tb -= BW_PF) {
 #pragma unroll
-            for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, t - 1, c, lane)];
-            un0 = u[tix<2>(tile, T, t - 1, 0, lane)];
-            un1 = u[tix<2>(tile, T, t - 1, 1, lane)];
+      for (int i = 0; i < BW_PF; i++) {
+        const int t = tb - i;
+        if (t < 0) break;
+        if (t == 0) {  // sample 0 is x0 (fp64), see load_state
+            load_state(x, x0, tile, T, 0, lane, xs);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; c++) xs[c] = (double)xb[i][c];
+        }
+        const double u0 = ubuf[i][0], u1 = ubuf[i][1];
+        {   // refill this slot with stage t - BW_PF (clamped at 0: the head re-reads stage 0)
+            const int tn = t - BW_PF >= 0 ? t - BW_PF : 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) xb[i][c] = x[tix<6>(tile, T, tn, c, lane)];
+            ubuf[i][0] = u[tix<2>(tile, T, tn, 0, lane)];
+            ubuf[i][1] = u[tix<2>(tile, T, tn, 1, lane)];
         }
         stage_cost<DIAG>(k, xs, u0, u1, ref + (size_t)t * 8, q, r);  // q = l_x, r = l_u (optcon.py:436)
         const SC s = trig(xs[3], xs[5]);
@@ -321,6 +366,7 @@ __global__ __launch_bounds__(TILE) void k_backward(KConst k, const double* __res
         for (int c = 0; c < 14; c++) Kt[tix<14>(tile, T, t, c, lane)] = Ks[c];
         g[tix<2>(tile, T, t, 0, lane)] = g0;
         g[tix<2>(tile, T, t, 1, lane)] = g1;
+      }
     }
     if (lmbd0) {
 #pragma unroll
@@ -332,14 +378,15 @@ __global__ __launch_bounds__(TILE) void k_backward(KConst k, const double* __res
 // Forward pass (see aoc_forward in include/aoc.h).  NSPEC = number of Armijo candidate steps
 // (alpha_0 .. alpha_{NSPEC-1}) whose trial rollouts ride along: the pass is bound by the K~ stream
 // from HBM, so a second serial chain in the same lane is nearly free and saves a whole
-// latency-bound trial round later.
-template <bool DIAG, int NSPEC, bool WRITE>
+// latency-bound trial round later.  Operands of the next FW_PF stages are in flight in a register ring.
+constexpr int FW_PF = 2;
+
+template <bool DIAG, int NSPEC, typename XT>
 __global__ __launch_bounds__(TILE) void k_forward(KConst k, aoc_params prm, const double* __restrict__ ref,
-                                                  const double* __restrict__ x, const double* __restrict__ u,
+                                                  const XT* __restrict__ x, const double* __restrict__ u,
                                                   const double* __restrict__ x0, const double* __restrict__ Kt,
                                                   const double* __restrict__ g, double* __restrict__ du_out,
-                                                  double* __restrict__ descent, double* __restrict__ x_new,
-                                                  double* __restrict__ u_new, double* __restrict__ J_trial,
+                                                  double* __restrict__ descent, double* __restrict__ J_trial,
                                                   int* __restrict__ status) {
     const int tile = blockIdx.x, lane = threadIdx.x, b = tile * TILE + lane, T = k.T;
     const int Bp = k.ntiles * TILE;
@@ -354,33 +401,45 @@ __global__ __launch_bounds__(TILE) void k_forward(KConst k, aoc_params prm, cons
         const double v = x0[((size_t)tile * 6 + c) * TILE + lane];
 #pragma unroll
         for (int j = 0; j < NSPEC; j++) xp[j][c] = v;
-        if (WRITE) x_new[tix<6>(tile, T, 0, c, lane)] = v;
     }
 #pragma unroll
     for (int j = 0; j < NSPEC; j++) JJ[j] = 0.0;
     double desc = 0.0;
-    // software prefetch of stage t+1 operands
-    double Kn[14], gn0, gn1, xn[6], un0, un1;
+    double Kb[FW_PF][14], gb[FW_PF][2], ub[FW_PF][2];
+    XT xb[FW_PF][6];
 #pragma unroll
-    for (int c = 0; c < 14; c++) Kn[c] = Kt[tix<14>(tile, T, 0, c, lane)];
-    gn0 = g[tix<2>(tile, T, 0, 0, lane)]; gn1 = g[tix<2>(tile, T, 0, 1, lane)];
+    for (int i = 0; i < FW_PF; i++) {
+        const int tp = i < T - 1 ? i : T - 2;
 #pragma unroll
-    for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, 0, c, lane)];
-    un0 = u[tix<2>(tile, T, 0, 0, lane)]; un1 = u[tix<2>(tile, T, 0, 1, lane)];
-    for (int t = 0; t < T - 1; t++) {
+        for (int c = 0; c < 14; c++) Kb[i][c] = Kt[tix<14>(tile, T, tp, c, lane)];
+        gb[i][0] = g[tix<2>(tile, T, tp, 0, lane)]; gb[i][1] = g[tix<2>(tile, T, tp, 1, lane)];
+#pragma unroll
+        for (int c = 0; c < 6; c++) xb[i][c] = x[tix<6>(tile, T, tp, c, lane)];
+        ub[i][0] = u[tix<2>(tile, T, tp, 0, lane)]; ub[i][1] = u[tix<2>(tile, T, tp, 1, lane)];
+    }
+    for (int t0 = 0; t0 < T - 1; t0 += FW_PF) {
+#pragma unroll
+      for (int i = 0; i < FW_PF; i++) {
+        const int t = t0 + i;
+        if (t >= T - 1) break;
         double Kc[14], xs[6];
 #pragma unroll
-        for (int c = 0; c < 14; c++) Kc[c] = Kn[c];
+        for (int c = 0; c < 14; c++) Kc[c] = Kb[i][c];
+        if (t == 0) {  // sample 0 is x0 (fp64), see load_state
+            load_state(x, x0, tile, T, 0, lane, xs);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 6; c++) xs[c] = xn[c];
-        const double g0 = gn0, g1 = gn1, uc0 = un0, uc1 = un1;
-        if (t + 1 < T - 1) {
+            for (int c = 0; c < 6; c++) xs[c] = (double)xb[i][c];
+        }
+        const double g0 = gb[i][0], g1 = gb[i][1], uc0 = ub[i][0], uc1 = ub[i][1];
+        {   // refill this slot with stage t + FW_PF (clamped: the tail re-reads the last stage)
+            const int tn = t + FW_PF < T - 1 ? t + FW_PF : T - 2;
 #pragma unroll
-            for (int c = 0; c < 14; c++) Kn[c] = Kt[tix<14>(tile, T, t + 1, c, lane)];
-            gn0 = g[tix<2>(tile, T, t + 1, 0, lane)]; gn1 = g[tix<2>(tile, T, t + 1, 1, lane)];
+            for (int c = 0; c < 14; c++) Kb[i][c] = Kt[tix<14>(tile, T, tn, c, lane)];
+            gb[i][0] = g[tix<2>(tile, T, tn, 0, lane)]; gb[i][1] = g[tix<2>(tile, T, tn, 1, lane)];
 #pragma unroll
-            for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, t + 1, c, lane)];
-            un0 = u[tix<2>(tile, T, t + 1, 0, lane)]; un1 = u[tix<2>(tile, T, t + 1, 1, lane)];
+            for (int c = 0; c < 6; c++) xb[i][c] = x[tix<6>(tile, T, tn, c, lane)];
+            ub[i][0] = u[tix<2>(tile, T, tn, 0, lane)]; ub[i][1] = u[tix<2>(tile, T, tn, 1, lane)];
         }
         // du_t = K~_t [1; dx_t]   (optcon.py:759)
         double d0 = Kc[0], d1 = Kc[7];
@@ -413,22 +472,13 @@ __global__ __launch_bounds__(TILE) void k_forward(KConst k, aoc_params prm, cons
             JJ[j] += stage_cost<DIAG>(k, xp[j], u0, u1, ref + (size_t)t * 8, q, r);
             const SC s2 = trig(xp[j][3], xp[j][5]);
             step_state(k, xp[j], u0, u1, s2, xpn);
-            if (WRITE && j == 0) {
-                u_new[tix<2>(tile, T, t, 0, lane)] = u0;
-                u_new[tix<2>(tile, T, t, 1, lane)] = u1;
-#pragma unroll
-                for (int c = 0; c < 6; c++) x_new[tix<6>(tile, T, t + 1, c, lane)] = xpn[c];
-            }
 #pragma unroll
             for (int c = 0; c < 6; c++) xp[j][c] = xpn[c];
         }
+      }
     }
     du_out[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
     du_out[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
-    if (WRITE) {
-        u_new[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
-        u_new[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
-    }
 #pragma unroll
     for (int j = 0; j < NSPEC; j++) {
         JJ[j] += term_cost<DIAG>(k, xp[j], ref + (size_t)(T - 1) * 8, q);
@@ -443,10 +493,10 @@ __global__ __launch_bounds__(TILE) void k_forward(KConst k, aoc_params prm, cons
 // LQR tracking (lqr_tracking.py:245-283): linearise about (x_opt,u_opt), non-augmented Riccati with
 // constant weights and S = 0, gains K (2x6), closed-loop nonlinear rollout.
 // ---------------------------------------------------------------------------------------------
-template <bool DIAG>
-__global__ __launch_bounds__(TILE) void k_track_gains(KConst k, const double* __restrict__ x,
-                                                      const double* __restrict__ u, double* __restrict__ Kout,
-                                                      int* __restrict__ status) {
+template <bool DIAG, typename XT>
+__global__ __launch_bounds__(TILE) void k_track_gains(KConst k, const XT* __restrict__ x,
+                                                      const double* __restrict__ u, const double* __restrict__ x_opt0,
+                                                      double* __restrict__ Kout, int* __restrict__ status) {
     const int tile = blockIdx.x, lane = threadIdx.x, T = k.T;
     double P[21], p[6], Qb[21], xs[6], xn[6];
     int flags = 0;
@@ -456,16 +506,14 @@ __global__ __launch_bounds__(TILE) void k_track_gains(KConst k, const double* __
 #pragma unroll
         for (int j = i; j < 6; j++) { P[sidx(i, j)] = k.QT[i * 6 + j]; Qb[sidx(i, j)] = k.Q[i * 6 + j]; }  // :716
     }
-#pragma unroll
-    for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, T - 2, c, lane)];
+    load_state(x, x_opt0, tile, T, T - 2, lane, xn);
     double un0 = u[tix<2>(tile, T, T - 2, 0, lane)];
     for (int t = T - 2; t >= 0; t--) {
 #pragma unroll
         for (int c = 0; c < 6; c++) xs[c] = xn[c];
         const double u0 = un0;
         if (t > 0) {
-#pragma unroll
-            for (int c = 0; c < 6; c++) xn[c] = x[tix<6>(tile, T, t - 1, c, lane)];
+            load_state(x, x_opt0, tile, T, t - 1, lane, xn);
             un0 = u[tix<2>(tile, T, t - 1, 0, lane)];
         }
         const SC s = trig(xs[3], xs[5]);
@@ -486,25 +534,28 @@ __global__ __launch_bounds__(TILE) void k_track_gains(KConst k, const double* __
     if (status && flags) status[tile * TILE + lane] |= flags;
 }
 
-__global__ __launch_bounds__(TILE) void k_track_rollout(KConst k, const double* __restrict__ x,
-                                                        const double* __restrict__ u, const double* __restrict__ Kin,
-                                                        const double* __restrict__ x0, double* __restrict__ x_reg,
-                                                        double* __restrict__ u_reg, int* __restrict__ status) {
+template <typename XT, typename XO>
+__global__ __launch_bounds__(TILE) void k_track_rollout(KConst k, const XT* __restrict__ x,
+                                                        const double* __restrict__ u, const double* __restrict__ x_opt0,
+                                                        const double* __restrict__ Kin, const double* __restrict__ x0,
+                                                        XO* __restrict__ x_reg, double* __restrict__ u_reg,
+                                                        int* __restrict__ status) {
     const int tile = blockIdx.x, lane = threadIdx.x, T = k.T;
-    double xs[6], xn[6];
+    double xs[6], xn[6], xo[6];
     int flags = 0;
 #pragma unroll
     for (int c = 0; c < 6; c++) {
         xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
-        x_reg[tix<6>(tile, T, 0, c, lane)] = xs[c];
+        x_reg[tix<6>(tile, T, 0, c, lane)] = (XO)xs[c];
     }
     for (int t = 0; t < T - 1; t++) {
         double d[6], u0, u1;
+        load_state(x, x_opt0, tile, T, t, lane, xo);
         {
 #pragma clang fp contract(off)
             // uu_reg = uu_opt + KK @ (xx_reg - xx_opt)   (lqr_tracking.py:280)
 #pragma unroll
-            for (int c = 0; c < 6; c++) d[c] = xs[c] - x[tix<6>(tile, T, t, c, lane)];
+            for (int c = 0; c < 6; c++) d[c] = xs[c] - xo[c];
             double a0 = 0.0, a1 = 0.0;
 #pragma unroll
             for (int c = 0; c < 6; c++) {
@@ -520,7 +571,7 @@ __global__ __launch_bounds__(TILE) void k_track_rollout(KConst k, const double* 
         u_reg[tix<2>(tile, T, t, 0, lane)] = u0;
         u_reg[tix<2>(tile, T, t, 1, lane)] = u1;
 #pragma unroll
-        for (int c = 0; c < 6; c++) { x_reg[tix<6>(tile, T, t + 1, c, lane)] = xn[c]; xs[c] = xn[c]; }
+        for (int c = 0; c < 6; c++) { x_reg[tix<6>(tile, T, t + 1, c, lane)] = (XO)xn[c]; xs[c] = xn[c]; }
     }
     u_reg[tix<2>(tile, T, T - 1, 0, lane)] = 0.0;
     u_reg[tix<2>(tile, T, T - 1, 1, lane)] = 0.0;
@@ -873,14 +924,14 @@ __global__ __launch_bounds__(TILE) void k_ls_trial(KConst k, aoc_params prm, con
 #pragma unroll
     for (int c = 0; c < 6; c++) xs[c] = x0[((size_t)tile * 6 + c) * TILE + hl];
     int f2 = 0;
-    const double Jt = rollout<DIAG, false>(k, ref, tile, hl, xs, u, du, a_r, false, nullptr, nullptr, f2);
+    const double Jt = rollout<DIAG, false, double>(k, ref, tile, hl, xs, u, du, a_r, false, nullptr, nullptr, f2);
     if (valid && !armijo_reject(Jt, J_cur[b], prm.cc, a_r, descent[b])) atomicMin(&sc.first_ok[b], r);
 }
 
-template <bool DIAG>
+template <bool DIAG, typename XO>
 __global__ __launch_bounds__(TILE) void k_ls_final(KConst k, int maxiters, const double* __restrict__ ref,
                                                    const double* __restrict__ u, const double* __restrict__ x0,
-                                                   const double* __restrict__ du, double* __restrict__ x_new,
+                                                   const double* __restrict__ du, XO* __restrict__ x_new,
                                                    double* __restrict__ u_new, double* __restrict__ J_new,
                                                    double* __restrict__ stepsize, int* __restrict__ ntrials,
                                                    int* __restrict__ status, LsScratch sc) {
@@ -900,7 +951,7 @@ __global__ __launch_bounds__(TILE) void k_ls_final(KConst k, int maxiters, const
     double xs[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) xs[c] = x0[((size_t)tile * 6 + c) * TILE + lane];
-    const double Jf = rollout<DIAG, true>(k, ref, tile, lane, xs, u, du, a, true, x_new, u_new, flags);
+    const double Jf = rollout<DIAG, true, XO>(k, ref, tile, lane, xs, u, du, a, true, x_new, u_new, flags);
     if (Jf != Jf || Jf - Jf != 0.0) flags |= AOC_ST_NAN;
     J_new[b] = Jf;
     if (status && flags) status[b] |= flags;
@@ -980,14 +1031,28 @@ size_t aoc_tiled_elems(int32_t B, int32_t T, int32_t C) { return (size_t)aoc_nti
 int aoc_pack(int32_t B, int32_t T, int32_t C, const double* src, double* dst, void* stream) {
     if (!src || !dst || B < 1 || T < 1 || C < 1) return AOC_EINVAL;
     dim3 grid(aoc_ntiles(B), T < 64 ? T : 64);
-    hipLaunchKernelGGL(k_pack, grid, dim3(TILE), 0, (hipStream_t)stream, B, T, C, src, dst);
+    hipLaunchKernelGGL(k_pack<double>, grid, dim3(TILE), 0, (hipStream_t)stream, B, T, C, src, dst);
     return check_launch("k_pack");
 }
 
 int aoc_unpack(int32_t B, int32_t T, int32_t C, const double* src, double* dst, void* stream) {
     if (!src || !dst || B < 1 || T < 1 || C < 1) return AOC_EINVAL;
     dim3 grid(aoc_ntiles(B), T < 64 ? T : 64);
-    hipLaunchKernelGGL(k_unpack, grid, dim3(TILE), 0, (hipStream_t)stream, B, T, C, src, dst);
+    hipLaunchKernelGGL(k_unpack<double>, grid, dim3(TILE), 0, (hipStream_t)stream, B, T, C, src, dst);
+    return check_launch("k_unpack");
+}
+
+int aoc_pack_f32(int32_t B, int32_t T, int32_t C, const double* src, float* dst, void* stream) {
+    if (!src || !dst || B < 1 || T < 1 || C < 1) return AOC_EINVAL;
+    dim3 grid(aoc_ntiles(B), T < 64 ? T : 64);
+    hipLaunchKernelGGL(k_pack<float>, grid, dim3(TILE), 0, (hipStream_t)stream, B, T, C, src, dst);
+    return check_launch("k_pack");
+}
+
+int aoc_unpack_f32(int32_t B, int32_t T, int32_t C, const float* src, double* dst, void* stream) {
+    if (!src || !dst || B < 1 || T < 1 || C < 1) return AOC_EINVAL;
+    dim3 grid(aoc_ntiles(B), T < 64 ? T : 64);
+    hipLaunchKernelGGL(k_unpack<float>, grid, dim3(TILE), 0, (hipStream_t)stream, B, T, C, src, dst);
     return check_launch("k_unpack");
 }
 
@@ -1013,28 +1078,30 @@ int aoc_cost_batch(const aoc_problem* prob, int32_t n, const double* x, const do
     return check_launch("k_cost_batch");
 }
 
-int aoc_traj_cost(const aoc_problem* p, const double* x, const double* u, double* J) {
+int aoc_traj_cost(const aoc_problem* p, const void* x, const double* u, const double* x0, double* J) {
     int rc = check_problem(p);
     if (rc) return rc;
-    if (!x || !u || !J) return AOC_EINVAL;
+    if (!x || !u || !x0 || !J) return AOC_EINVAL;
     KConst k = make_const(p);
     hipStream_t st = (hipStream_t)p->stream;
-    if (k.diag) hipLaunchKernelGGL(k_traj_cost<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, x, u, J);
-    else hipLaunchKernelGGL(k_traj_cost<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, x, u, J);
+    AOC_DISPATCH_BOOL(k.diag, D, AOC_DISPATCH_XT(p->x_in_f32, XT,
+        hipLaunchKernelGGL((k_traj_cost<D, XT>), dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, (const XT*)x, u, x0, J)));
     return check_launch("k_traj_cost");
 }
 
-int aoc_initial_trajectory(const aoc_problem* p, double kp, double kt, const double* x0, double* x, double* u) {
+int aoc_initial_trajectory(const aoc_problem* p, double kp, double kt, const double* x0, void* x, double* u) {
     int rc = check_problem(p);
     if (rc) return rc;
     if (!x0 || !x || !u) return AOC_EINVAL;
     KConst k = make_const(p);
-    hipLaunchKernelGGL(k_initial_traj, dim3(k.ntiles), dim3(TILE), 0, (hipStream_t)p->stream, k, kp, kt, p->ref, x0, x, u);
+    AOC_DISPATCH_XT(p->x_out_f32, XO,
+        hipLaunchKernelGGL((k_initial_traj<XO>), dim3(k.ntiles), dim3(TILE), 0, (hipStream_t)p->stream, k, kp, kt,
+                           p->ref, x0, (XO*)x, u));
     return check_launch("k_initial_traj");
 }
 
 int aoc_rollout_cost(const aoc_problem* p, const double* x0, const double* u, const double* du,
-                     const double* alpha, double* x_out, double* u_out, double* J_out, int32_t* status) {
+                     const double* alpha, void* x_out, double* u_out, double* J_out, int32_t* status) {
     int rc = check_problem(p);
     if (rc) return rc;
     if (!x0 || !u || !J_out) return AOC_EINVAL;
@@ -1042,54 +1109,41 @@ int aoc_rollout_cost(const aoc_problem* p, const double* x0, const double* u, co
     if (du && !alpha) return AOC_EINVAL;
     KConst k = make_const(p);
     hipStream_t st = (hipStream_t)p->stream;
-    const bool w = x_out != nullptr;
-#define LAUNCH_RC(D, W)                                                                                         \
-    hipLaunchKernelGGL((k_rollout_cost<D, W>), dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, x0, u, du, alpha, \
-                       x_out, u_out, J_out, status)
-    if (k.diag) { if (w) LAUNCH_RC(true, true); else LAUNCH_RC(true, false); }
-    else { if (w) LAUNCH_RC(false, true); else LAUNCH_RC(false, false); }
-#undef LAUNCH_RC
+    AOC_DISPATCH_BOOL(k.diag, D, AOC_DISPATCH_BOOL(x_out != nullptr, W, AOC_DISPATCH_XT(p->x_out_f32, XO,
+        hipLaunchKernelGGL((k_rollout_cost<D, W, XO>), dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, x0, u, du, alpha,
+                           (XO*)x_out, u_out, J_out, status))));
     return check_launch("k_rollout_cost");
 }
 
-int aoc_backward(const aoc_problem* p, int32_t full_hessian, const double* x, const double* u, double* Kt,
-                 double* g, double* lmbd0, int32_t* status) {
+int aoc_backward(const aoc_problem* p, int32_t full_hessian, const void* x, const double* u, const double* x0,
+                 double* Kt, double* g, double* lmbd0, int32_t* status) {
     int rc = check_problem(p);
     if (rc) return rc;
-    if (!x || !u || !Kt || !g) return AOC_EINVAL;
+    if (!x || !u || !x0 || !Kt || !g) return AOC_EINVAL;
     KConst k = make_const(p);
     hipStream_t st = (hipStream_t)p->stream;
-#define LAUNCH_BW(D, F) \
-    hipLaunchKernelGGL((k_backward<D, F>), dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, x, u, Kt, g, lmbd0, status)
-    if (k.diag) { if (full_hessian) LAUNCH_BW(true, true); else LAUNCH_BW(true, false); }
-    else { if (full_hessian) LAUNCH_BW(false, true); else LAUNCH_BW(false, false); }
-#undef LAUNCH_BW
+    AOC_DISPATCH_BOOL(k.diag, D, AOC_DISPATCH_BOOL(full_hessian != 0, F, AOC_DISPATCH_XT(p->x_in_f32, XT,
+        hipLaunchKernelGGL((k_backward<D, F, XT>), dim3(k.ntiles), dim3(TILE), 0, st, k, p->ref, (const XT*)x, u, x0, Kt,
+                           g, lmbd0, status))));
     return check_launch("k_backward");
 }
 
-int aoc_forward(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const double* x, const double* u,
-                const double* x0, const double* Kt, const double* g, double* du, double* descent, double* x_new,
-                double* u_new, double* J_trial, int32_t* status) {
+int aoc_forward(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const void* x, const double* u,
+                const double* x0, const double* Kt, const double* g, double* du, double* descent, double* J_trial,
+                int32_t* status) {
     int rc = check_problem(p);
     if (rc) return rc;
     if (!prm || !x || !u || !x0 || !Kt || !g || !du || !descent || !J_trial) return AOC_EINVAL;
-    if ((x_new == nullptr) != (u_new == nullptr)) return AOC_EINVAL;
     if (n_spec < 1 || n_spec > 3) return AOC_EINVAL;
     KConst k = make_const(p);
     hipStream_t st = (hipStream_t)p->stream;
-    const bool w = x_new != nullptr;
-#define LAUNCH_FW(D, N, W)                                                                                         \
-    hipLaunchKernelGGL((k_forward<D, N, W>), dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, p->ref, x, u, x0, Kt, g, du, \
-                       descent, x_new, u_new, J_trial, status)
-#define LAUNCH_FW_N(D, W)                                        \
-    do {                                                         \
-        if (n_spec == 1) LAUNCH_FW(D, 1, W);                     \
-        else if (n_spec == 2) LAUNCH_FW(D, 2, W);                \
-        else LAUNCH_FW(D, 3, W);                                 \
-    } while (0)
-    if (k.diag) { if (w) LAUNCH_FW_N(true, true); else LAUNCH_FW_N(true, false); }
-    else { if (w) LAUNCH_FW_N(false, true); else LAUNCH_FW_N(false, false); }
-#undef LAUNCH_FW_N
+#define LAUNCH_FW(N)                                                                                                \
+    AOC_DISPATCH_BOOL(k.diag, D, AOC_DISPATCH_XT(p->x_in_f32, XT,                                                   \
+        hipLaunchKernelGGL((k_forward<D, N, XT>), dim3(k.ntiles), dim3(TILE), 0, st, k, *prm, p->ref, (const XT*)x, \
+                           u, x0, Kt, g, du, descent, J_trial, status)))
+    if (n_spec == 1) LAUNCH_FW(1);
+    else if (n_spec == 2) LAUNCH_FW(2);
+    else LAUNCH_FW(3);
 #undef LAUNCH_FW
     return check_launch("k_forward");
 }
@@ -1104,7 +1158,7 @@ size_t aoc_linesearch_scratch_bytes(int32_t B) {
 
 int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const double* u, const double* x0,
                    const double* du, const double* J_cur, const double* descent, const double* J_trial0,
-                   double* x_new, double* u_new, double* J_new, double* stepsize, int32_t* ntrials, int32_t* status,
+                   void* x_new, double* u_new, double* J_new, double* stepsize, int32_t* ntrials, int32_t* status,
                    void* scratch) {
     int rc = check_problem(p);
     if (rc) return rc;
@@ -1138,28 +1192,27 @@ int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, 
             hipLaunchKernelGGL(k_ls_trial<false>, dim3(wcap), dim3(TILE), 0, st, k, *prm, p->ref, u, x0, du, J_cur,
                                descent, sc);
     }
-    if (k.diag)
-        hipLaunchKernelGGL(k_ls_final<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, prm->armijo_maxiters, p->ref, u, x0,
-                           du, x_new, u_new, J_new, stepsize, ntrials, status, sc);
-    else
-        hipLaunchKernelGGL(k_ls_final<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, prm->armijo_maxiters, p->ref, u, x0,
-                           du, x_new, u_new, J_new, stepsize, ntrials, status, sc);
+    AOC_DISPATCH_BOOL(k.diag, D, AOC_DISPATCH_XT(p->x_out_f32, XO,
+        hipLaunchKernelGGL((k_ls_final<D, XO>), dim3(k.ntiles), dim3(TILE), 0, st, k, prm->armijo_maxiters, p->ref, u, x0,
+                           du, (XO*)x_new, u_new, J_new, stepsize, ntrials, status, sc)));
     return check_launch("aoc_linesearch");
 }
 
-int aoc_lqr_tracking(const aoc_problem* p, const double* x_opt, const double* u_opt, const double* x0_reg,
-                     double* Kgain, double* x_reg, double* u_reg, int32_t* status) {
+int aoc_lqr_tracking(const aoc_problem* p, const void* x_opt, const double* u_opt, const double* x_opt0,
+                     const double* x0_reg, double* Kgain, void* x_reg, double* u_reg, int32_t* status) {
     int rc = check_problem(p);
     if (rc) return rc;
-    if (!x_opt || !u_opt || !Kgain) return AOC_EINVAL;
+    if (!x_opt || !u_opt || !x_opt0 || !Kgain) return AOC_EINVAL;
     if ((x_reg == nullptr) != (u_reg == nullptr) || (x_reg && !x0_reg)) return AOC_EINVAL;
     KConst k = make_const(p);
     hipStream_t st = (hipStream_t)p->stream;
-    if (k.diag) hipLaunchKernelGGL(k_track_gains<true>, dim3(k.ntiles), dim3(TILE), 0, st, k, x_opt, u_opt, Kgain, status);
-    else hipLaunchKernelGGL(k_track_gains<false>, dim3(k.ntiles), dim3(TILE), 0, st, k, x_opt, u_opt, Kgain, status);
+    AOC_DISPATCH_BOOL(k.diag, D, AOC_DISPATCH_XT(p->x_in_f32, XT,
+        hipLaunchKernelGGL((k_track_gains<D, XT>), dim3(k.ntiles), dim3(TILE), 0, st, k, (const XT*)x_opt, u_opt, x_opt0,
+                           Kgain, status)));
     if (x_reg)
-        hipLaunchKernelGGL(k_track_rollout, dim3(k.ntiles), dim3(TILE), 0, st, k, x_opt, u_opt, Kgain, x0_reg, x_reg,
-                           u_reg, status);
+        AOC_DISPATCH_XT(p->x_in_f32, XT, AOC_DISPATCH_XT(p->x_out_f32, XO,
+            hipLaunchKernelGGL((k_track_rollout<XT, XO>), dim3(k.ntiles), dim3(TILE), 0, st, k, (const XT*)x_opt, u_opt,
+                               x_opt0, Kgain, x0_reg, (XO*)x_reg, u_reg, status)));
     return check_launch("aoc_lqr_tracking");
 }
 
@@ -1184,8 +1237,8 @@ size_t aoc_workspace_bytes(int32_t B, int32_t T) {
            aoc_linesearch_scratch_bytes(B);
 }
 
-int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, const double* x, const double* u,
-                       const double* x0, const double* J_cur, void* workspace, double* x_new, double* u_new,
+int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, const void* x, const double* u,
+                       const double* x0, const double* J_cur, void* workspace, void* x_new, double* u_new,
                        double* J_new, double* descent, double* stepsize, int32_t* ntrials, int32_t* status) {
     int rc = check_problem(p);
     if (rc) return rc;
@@ -1193,12 +1246,12 @@ int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, 
     double* Kt = (double*)workspace;
     double* g = Kt + aoc_tiled_elems(p->B, p->T, 14);
     double* du = g + aoc_tiled_elems(p->B, p->T, 2);
-    rc = aoc_backward(p, kk > prm->hessian_switch, x, u, Kt, g, nullptr, status);
-    if (rc) return rc;
     double* J_trial = du + aoc_tiled_elems(p->B, p->T, 2);
     void* scratch = (void*)(J_trial + 3 * (size_t)aoc_ntiles(p->B) * TILE);
     static const int nspec = getenv("AOC_NSPEC") ? atoi(getenv("AOC_NSPEC")) : 2;
-    rc = aoc_forward(p, prm, nspec, x, u, x0, Kt, g, du, descent, nullptr, nullptr, J_trial, status);
+    rc = aoc_backward(p, kk > prm->hessian_switch, x, u, x0, Kt, g, nullptr, status);
+    if (rc) return rc;
+    rc = aoc_forward(p, prm, nspec, x, u, x0, Kt, g, du, descent, J_trial, status);
     if (rc) return rc;
     return aoc_linesearch(p, prm, nspec, u, x0, du, J_cur, descent, J_trial, x_new, u_new, J_new, stepsize, ntrials,
                           status, scratch);

@@ -23,7 +23,18 @@
  *   contiguous bytes per (t, component) and walks its own contiguous slab over the horizon.
  *   aoc_pack()/aoc_unpack() convert from/to the reference's per-trajectory (C,T) C-order arrays
  *   stacked as (B,C,T).  Lanes of the last tile beyond B replicate trajectory B-1.
- *   Per-trajectory scalars are plain arrays of length ntiles*64.
+ *   Per-trajectory scalars are plain arrays of length ntiles*64; per-trajectory 6-vectors (x0) are
+ *   [ntiles][6][64] fp64.
+ *
+ * State storage
+ *   Every state the reference propagates is a float32 value widened to fp64: Dynamics.step writes
+ *   its result into a float32 array (aircraft_simplified.py:300).  State trajectories (the tiled C=6
+ *   arrays `x`, `x_new`, `x_opt`, `x_reg`, declared `void*`) may therefore be stored as float32 without
+ *   loss for samples t >= 1, which halves their HBM traffic.  Sample 0 is x0 — any fp64 value — and is
+ *   ALWAYS taken from the separate fp64 `x0` argument, never from the array.  aoc_problem.x_in_f32 /
+ *   x_out_f32 select the element type of the state arrays a call reads / writes.  A caller-supplied
+ *   initial iterate with arbitrary fp64 samples must be passed as fp64 (x_in_f32 = 0).
+ *   Inputs u, du, gains and costs are always fp64.
  */
 #ifndef AOC_H
 #define AOC_H
@@ -70,6 +81,8 @@ typedef struct aoc_problem {
     double QQT[36];   /* row-major 6x6 */
     int32_t B;        /* trajectories */
     int32_t T;        /* samples per trajectory = int(tf/dt), optcon.py:378 (T-1 stages) */
+    int32_t x_in_f32; /* element type of the tiled STATE arrays a call reads: 0 = fp64, 1 = float32 */
+    int32_t x_out_f32;/* ... and of those it writes (see "State storage" above) */
     const double *ref;/* DEVICE, shared by the batch, time-major [T][8]: xx_ref[0..5,t], uu_ref[0..1,t] */
     void *stream;     /* hipStream_t */
 } aoc_problem;
@@ -98,6 +111,9 @@ int32_t aoc_ntiles(int32_t B);
  * layout.  src/dst are device pointers. */
 int aoc_pack(int32_t B, int32_t T, int32_t C, const double *src_bct, double *dst_tiled, void *stream);
 int aoc_unpack(int32_t B, int32_t T, int32_t C, const double *src_tiled, double *dst_bct, void *stream);
+/* same with a float32 tiled array (state storage) */
+int aoc_pack_f32(int32_t B, int32_t T, int32_t C, const double *src_bct, float *dst_tiled, void *stream);
+int aoc_unpack_f32(int32_t B, int32_t T, int32_t C, const float *src_tiled, double *dst_bct, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Unit level
@@ -120,21 +136,21 @@ int aoc_cost_batch(const aoc_problem *prob, int32_t n, const double *x, const do
  * --------------------------------------------------------------------------------------------- */
 
 /* Cost of a stored trajectory: the loop at optcon.py:417-424.  J[ntiles*64]. */
-int aoc_traj_cost(const aoc_problem *prob, const double *x, const double *u, double *J);
+int aoc_traj_cost(const aoc_problem *prob, const void *x, const double *u, const double *x0, double *J);
 
 /* Dynamics.get_initial_trajectory (aircraft_simplified.py:126-148): P-controller rollout
  *   u_i = [kp((X-Xr)+(Z-Zr)), kt((th-thr)+(ga-gar))] against xx_ref[:, i+1], from x0 ([ntiles][6][64]).
  * The reference uses kp = 5, kt = 2.5.  Evaluated in fp64 with the float32 state rounding of step();
  * the reference's own call runs mostly in float32 (it feeds step() its float32 output), so results
  * agree to ~1e-4 only — this produces an initial GUESS.  x, u tiled outputs. */
-int aoc_initial_trajectory(const aoc_problem *prob, double kp, double kt, const double *x0, double *x, double *u);
+int aoc_initial_trajectory(const aoc_problem *prob, double kp, double kt, const double *x0, void *x, double *u);
 
 /* get_update (optcon.py:176-200) fused with the cost loop of one Armijo trial (optcon.py:250-264):
  * u' = u + alpha[b]*du, x' rolled out from x0 with the float32 state rounding, J' accumulated.
  * x0 [ntiles][6][64]; alpha, J_out [ntiles*64]; du may be NULL (alpha ignored: plain rollout of u).
  * x_out/u_out may be NULL (cost only).  status is OR-ed. */
 int aoc_rollout_cost(const aoc_problem *prob, const double *x0, const double *u, const double *du,
-                     const double *alpha, double *x_out, double *u_out, double *J_out, int32_t *status);
+                     const double *alpha, void *x_out, double *u_out, double *J_out, int32_t *status);
 
 /* Backward pass of one Newton iteration: terminal condition, costate sweep, quadratisation
  * (Gauss-Newton or full Hessian) and the affine Riccati/gain recursion of ltv_LQR, fused
@@ -142,19 +158,18 @@ int aoc_rollout_cost(const aoc_problem *prob, const double *x0, const double *u,
  * columns 1..6 feedback K) as 14 components and g = B^T lambda_{t+1} + r (2 components).
  * Kt: tiled C=14 over T samples (sample T-1 unused), g: tiled C=2.
  * lmbd0 (optional, [ntiles][6][64]) receives lambda_0. */
-int aoc_backward(const aoc_problem *prob, int32_t full_hessian, const double *x, const double *u,
-                 double *Kt, double *g, double *lmbd0, int32_t *status);
+int aoc_backward(const aoc_problem *prob, int32_t full_hessian, const void *x, const double *u,
+                 const double *x0, double *Kt, double *g, double *lmbd0, int32_t *status);
 
 /* Forward pass: closed-loop linear rollout of ltv_LQR (optcon.py:756-762) giving du, the descent
  * sum (optcon.py:474-477), fused with the first n_spec (1..3) Armijo trials: for step
  * alpha_j = stepsize_0*beta^j, u' = u + alpha_j*du, nonlinear rollout x' from x0, cost J'_j
  * (optcon.py:250-264).  The pass is bound by the K~ stream, so trials 1.. ride along for free; the
  * reference evaluates them one after the other, the verdict order is kept by aoc_linesearch.
- * Outputs: du (tiled C=2), descent[ntiles*64], J_trial[n_spec][ntiles*64]; x_new/u_new (tiled)
- * receive the alpha_0 trial trajectory when non-NULL (both or neither). */
-int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const double *x, const double *u,
+ * Outputs: du (tiled C=2), descent[ntiles*64], J_trial[n_spec][ntiles*64]. */
+int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const void *x, const double *u,
                 const double *x0, const double *Kt, const double *g, double *du, double *descent,
-                double *x_new, double *u_new, double *J_trial, int32_t *status);
+                double *J_trial, int32_t *status);
 
 /* Armijo back-tracking (optcon.py:243-273) and the final update (optcon.py:488-491).
  * Trial ii uses alpha_ii = stepsize_0*beta^ii and is accepted iff J'(alpha_ii) <= J_cur +
@@ -168,16 +183,17 @@ int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, 
 size_t aoc_linesearch_scratch_bytes(int32_t B);
 int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const double *u,
                    const double *x0, const double *du, const double *J_cur, const double *descent,
-                   const double *J_trial, double *x_new, double *u_new, double *J_new, double *stepsize,
+                   const double *J_trial, void *x_new, double *u_new, double *J_new, double *stepsize,
                    int32_t *ntrials, int32_t *status, void *scratch);
 
 /* lqr_tracking.lqr_tracking (lqr_tracking.py:245-283): linearise about (x_opt,u_opt), non-augmented
  * Riccati/gain recursion with the constant weights QQt,RRt,QQT of `prob` and S = 0
  * (lqr_tracking.py:276), then the closed-loop nonlinear rollout u = u_opt + K (x - x_opt) from
- * x0_reg (= x_opt[:,0] + perturbation, [ntiles][6][64]).  Kgain: tiled C=12 (row 0 then row 1 of the
- * 2x6 gain; sample T-1 zero).  x_reg/u_reg/x0_reg may be NULL (gains only). */
-int aoc_lqr_tracking(const aoc_problem *prob, const double *x_opt, const double *u_opt, const double *x0_reg,
-                     double *Kgain, double *x_reg, double *u_reg, int32_t *status);
+ * x0_reg (= x_opt[:,0] + perturbation).  x_opt0 = sample 0 of x_opt, x0_reg: [ntiles][6][64] fp64.
+ * Kgain: tiled C=12 (row 0 then row 1 of the 2x6 gain; sample T-1 zero).  x_reg/u_reg/x0_reg may be
+ * NULL (gains only). */
+int aoc_lqr_tracking(const aoc_problem *prob, const void *x_opt, const double *u_opt, const double *x_opt0,
+                     const double *x0_reg, double *Kgain, void *x_reg, double *u_reg, int32_t *status);
 
 /* optcon.ltv_LQR(AAin,BBin,QQin,RRin,SSin,QQfin,TT,x0,qq,rr,qqf)  (optcon.py:533-771; identical copy
  * lqr_tracking.py:6-242) for nb independent problems with caller-supplied per-stage matrices, in
@@ -203,9 +219,9 @@ size_t aoc_workspace_bytes(int32_t B, int32_t T);
  * recomputes the same number, optcon.py:417-424).  Results: x_new,u_new,J_new and the
  * per-trajectory scalars descent, stepsize, ntrials.  No trajectory is skipped (fixed-iteration
  * mode); convergence bookkeeping is the caller's (aoc_newton_solve does it). */
-int aoc_newton_iterate(const aoc_problem *prob, const aoc_params *prm, int32_t kk, const double *x,
+int aoc_newton_iterate(const aoc_problem *prob, const aoc_params *prm, int32_t kk, const void *x,
                        const double *u, const double *x0, const double *J_cur, void *workspace,
-                       double *x_new, double *u_new, double *J_new, double *descent, double *stepsize,
+                       void *x_new, double *u_new, double *J_new, double *descent, double *stepsize,
                        int32_t *ntrials, int32_t *status);
 
 #ifdef __cplusplus

@@ -36,11 +36,11 @@ def test_geometry_helpers_and_errors():
     assert lib.aoc_strerror(-1) == b"invalid argument"
     # struct layout must match the header: 9 doubles + 76 doubles + 2 int32 + 2 pointers
     assert C.sizeof(_lib.Model) == 72
-    assert C.sizeof(_lib.Problem) == 72 + 76 * 8 + 8 + 16
+    assert C.sizeof(_lib.Problem) == 72 + 76 * 8 + 16 + 16
     assert C.sizeof(_lib.Params) == 48
     # argument errors are reported before anything touches a device
     p = _lib.Problem()
-    assert lib.aoc_traj_cost(C.byref(p), None, None, None) == -1
+    assert lib.aoc_traj_cost(C.byref(p), None, None, None, None) == -1
     assert lib.aoc_pack(0, 10, 6, None, None, None) == -1
 
 

@@ -129,20 +129,25 @@ def test_rollout_cost_vs_oracle(aoc):
     _, _, J2, _ = aoc.rollout_cost(bp, x0, uu, du, alpha, write=False)
     assert np.array_equal(J, J2)
     assert np.array_equal(aoc.traj_cost(bp, xx, un), J)
+    # float32 state storage on the device returns the same trajectory
+    xf, uf, Jf, _ = aoc.rollout_cost(bp, x0, uu, du, alpha, f32=True)
+    assert np.array_equal(xf, xx) and np.array_equal(uf, un) and np.array_equal(Jf, J)
 
 
 LQR_CASES = [("a_gn_init_T1000", "problem_step_T1000", 1e-8), ("b_full_init_T1000", "problem_step_T1000", 1e-5),
              ("c_full_near_T500", "problem_step_T500", 1e-8), ("d_gn_init_T500", "problem_step_T500", 1e-8)]
 
 
+@pytest.mark.parametrize("f32", [False, True])
 @pytest.mark.parametrize("case,prob,tol", LQR_CASES)
-def test_backward_forward_vs_golden(aoc, case, prob, tol):
+def test_backward_forward_vs_golden(aoc, case, prob, tol, f32):
     """Fused backward pass (costate + quadratisation + Riccati + gains) and LQR rollout against the
-    reference's ltv_LQR outputs, incl. the regularisation branch (case b: 18 stages)."""
+    reference's ltv_LQR outputs, incl. the regularisation branch (case b: 18 stages); with the state
+    trajectory handed over as fp64 and as float32 (identical values: the iterates are float32-valued)."""
     g = load_golden("g3_lqr_" + case)
     _, bp, op = _problem(aoc, prob)
     fh = int(g["full_hessian"])
-    r = aoc.backward_forward(bp, g["xx"][None], g["uu"][None], fh)
+    r = aoc.backward_forward(bp, g["xx"][None], g["uu"][None], fh, f32=f32)
     KK = r["KK"][0]
     assert scaled_err(KK[:, :, :-1], g["KK"][:, :, :-1]) < tol
     assert rel_err(r["du"][0], g["du"], 1e-3) < tol
@@ -150,9 +155,13 @@ def test_backward_forward_vs_golden(aoc, case, prob, tol):
     assert rel_err(r["lmbd0"][0], g["lmbd"][:, 0], 1e-9) < 1e-9
     from aircraftoptimalcontrol_amd import _lib
     assert bool(r["status"][0] & _lib.ST_REGULARISED) == (int(g["n_regularised"]) > 0)
-    # first Armijo trial = get_update(stepsize_0) of the oracle on the reference's du
-    xo, uo = orc.get_update(op, 1.0, g["uu"], g["du"], g["xx"][:, 0])
-    assert rel_err(r["uu_new"][0], uo, 1e-3) < tol
+    # cost of the first Armijo trial = cost of the oracle's get_update(stepsize_0) on the SAME du
+    xo, uo = orc.get_update(op, 1.0, g["uu"], r["du"][0], g["xx"][:, 0])
+    assert r["J_trial0"][0] == orc.traj_cost(op, xo, uo)
+    if f32:  # both storage types give bit-identical results
+        r64 = aoc.backward_forward(bp, g["xx"][None], g["uu"][None], fh, f32=False)
+        for key in ("KK", "du", "descent", "J_trial0", "lmbd0"):
+            assert np.array_equal(r[key], r64[key]), key
 
 
 # ----------------------------------------------------------------------------------------------
@@ -361,3 +370,39 @@ def test_shard_invariance_and_large_batch(aoc):
     acc = last["ntrials"] < 10
     assert np.all(last["cost_new"][acc] <= last["cost"][acc] + 0.5 * last["stepsize"][acc] * last["descent"][acc])
     assert np.all(last["descent"] < 0) and not last["status"].any()
+
+
+def test_initial_iterate_with_arbitrary_fp64_samples(aoc):
+    """The reference linearises iteration 0 about xx_init as given (optcon.py:395, :436-437), which need
+    not be float32-valued.  Such an iterate is kept in fp64 for the first iteration; checked against
+    the oracle on an initial state trajectory that is the (smooth, fp64) reference curve itself, and
+    returned verbatim when a trajectory stops after one iteration."""
+    g, bp, op = _problem(aoc, "problem_step_T500")
+    c = load_golden("g6_chain_step_T500")
+    xx0 = g["xx_ref"].copy() + 1e-3 * np.sin(np.arange(500))[None, :]   # not float32-representable
+    xx0[:, 0] = c["xx_init"][:, 0]
+    uu0 = c["uu_init"].copy()
+    assert not np.array_equal(xx0[:, 1:].astype(np.float32).astype(np.float64), xx0[:, 1:])
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    s = aoc.NewtonBatchSolver(bp, 2, prm)
+    s.set_initial(np.stack([xx0, c["xx_init"]]), np.stack([uu0, c["uu_init"]]))
+    assert s.cur_is64
+    xi, ui = s.current()
+    assert np.array_equal(xi[0], xx0) and np.array_equal(xi[1], c["xx_init"])
+    s.iterate(0)
+    sc = s.scalars()
+    xn, un = s.current()
+    oprm = orc.params()
+    for b, (xa, ua) in enumerate(((xx0, uu0), (c["xx_init"], c["uu_init"]))):
+        r = orc.newton_iterate(op, oprm, 0, xa, ua, xa[:, 0])
+        assert r["stepsize"] == sc["stepsize"][b] and r["ntrials"] == sc["ntrials"][b]
+        assert abs(r["J"] - sc["cost"][b]) <= 1e-12 * abs(r["J"])
+        assert abs(r["descent"] - sc["descent"][b]) <= 1e-8 * abs(r["descent"])
+        assert np.array_equal(xn[b], r["xx"]) and rel_err(un[b], r["uu"], 1e-3) < 1e-8
+    # stop after iteration 1 (term_cond huge): the reference returns history index 0 = xx_init itself
+    prm2 = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10, term_cond=-1e30)
+    s2 = aoc.NewtonBatchSolver(bp, 2, prm2)
+    s2.set_initial(np.stack([xx0, c["xx_init"]]), np.stack([uu0, c["uu_init"]]))
+    r2 = s2.solve()
+    # descent >= -1e30 at kk = 0 already: index -1 = the all-zero slot (Q7)
+    assert r2["iters"].tolist() == [1, 1] and not r2["xx_star"].any() and not r2["uu_star"].any()
