@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_PKG, "lib", "libaoc_hip.so")
+_SO = os.environ.get("AOC_LIB") or os.path.join(_PKG, "lib", "libaoc_hip.so")  # AOC_LIB: experiment builds
 _SRC = [os.path.join(_PKG, "csrc", f) for f in ("aoc_kernels.hip", "aoc_device.h")]
 _HDR = os.path.join(os.path.dirname(_PKG), "include", "aoc.h")
 

@@ -162,7 +162,10 @@ __global__ __launch_bounds__(TILE) void k_traj_cost(KConst k, const double* __re
 // WRITE: store x',u'.  wmask: lane writes only if true.
 // The loop carries a strictly serial chain (x_t -> x_{t+1}), so the only way to keep HBM busy from
 // one wavefront is to run the (u, du) loads far ahead: a register ring of ROLL_PF stages.
-constexpr int ROLL_PF = 8;
+#ifndef AOC_ROLL_PF
+#define AOC_ROLL_PF 8
+#endif
+constexpr int ROLL_PF = AOC_ROLL_PF;
 
 template <bool DIAG, bool WRITE, typename XO>
 __device__ __forceinline__ double rollout(const KConst& k, const double* __restrict__ ref, int tile, int lane,
@@ -281,7 +284,10 @@ __global__ __launch_bounds__(TILE) void k_initial_traj(KConst k, double kp, doub
 
 // Backward pass (see aoc_backward in include/aoc.h).
 // The (x,u) loads of the next BW_PF stages are kept in flight in a register ring.
-constexpr int BW_PF = 1;
+#ifndef AOC_BW_PF
+#define AOC_BW_PF 1
+#endif
+constexpr int BW_PF = AOC_BW_PF;
 
 template <bool DIAG, bool FULL, typename XT>
 __global__ __launch_bounds__(TILE) void k_backward(KConst k, const double* __restrict__ ref,
@@ -379,7 +385,10 @@ __global__ __launch_bounds__(TILE) void k_backward(KConst k, const double* __res
 // (alpha_0 .. alpha_{NSPEC-1}) whose trial rollouts ride along: the pass is bound by the K~ stream
 // from HBM, so a second serial chain in the same lane is nearly free and saves a whole
 // latency-bound trial round later.  Operands of the next FW_PF stages are in flight in a register ring.
-constexpr int FW_PF = 2;
+#ifndef AOC_FW_PF
+#define AOC_FW_PF 2
+#endif
+constexpr int FW_PF = AOC_FW_PF;
 
 template <bool DIAG, int NSPEC, typename XT>
 __global__ __launch_bounds__(TILE) void k_forward(KConst k, aoc_params prm, const double* __restrict__ ref,
