@@ -138,9 +138,10 @@ def step_batch(model, x, u, lmbd=None, device="cuda:0"):
     """Dynamics.step for n points (reference aircraft_simplified.py:263-393).
     Returns numpy (xp, fx, fu, fxx, fuu, fux); the last three are None without lmbd."""
     torch = _torch()
-    xd, ud = _dev_f64(np.atleast_2d(x), device), _dev_f64(np.atleast_2d(u), device)
+    two_d = lambda a: a if isinstance(a, torch.Tensor) else np.atleast_2d(a)
+    xd, ud = _dev_f64(two_d(x), device), _dev_f64(two_d(u), device)
     n = xd.shape[0]
-    ld = None if lmbd is None else _dev_f64(np.atleast_2d(lmbd), device)
+    ld = None if lmbd is None else _dev_f64(two_d(lmbd), device)
     mk = lambda *s: torch.empty(s, dtype=torch.float64, device=xd.device)
     xp, fx, fu = mk(n, 6), mk(n, 6, 6), mk(n, 2, 6)
     fxx, fuu, fux = (mk(n, 6, 6), mk(n, 2, 2), mk(n, 2, 6)) if ld is not None else (None, None, None)
