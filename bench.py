@@ -77,11 +77,27 @@ def main():
     import torch.distributed as dist
     from aircraftoptimalcontrol_amd import batch, problems
 
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    # Rehearsal knobs (not used by the driver): AOC_BENCH_BACKEND=gloo runs the collectives over gloo on
+    # host copies, AOC_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 (several ranks on a one-GPU box).
+    backend = os.environ.get("AOC_BENCH_BACKEND", "nccl")
+    one_dev = os.environ.get("AOC_BENCH_ONE_DEVICE", "0") == "1"
+    dev = torch.device("cuda", 0 if (world == 1 or one_dev) else local_rank)
     torch.cuda.set_device(dev)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def all_reduce(t, op):
+        if world == 1:
+            return t
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+            return t
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        return h.to(t.device)
 
     Bg, T = a.batch_per_gpu, a.horizon
     pr = problems.step_maneuver(tf=1.0, dt=1.0 / T)
@@ -108,9 +124,7 @@ def main():
                          s.ntrials[:Bg].sum().to(torch.float64),
                          torch.tensor(float(Bg), dtype=torch.float64, device=dev),
                          (~ok).sum().to(torch.float64)])
-        if world > 1:
-            dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        return v
+        return all_reduce(v, dist.ReduceOp.SUM)
 
     # warmup: W iterations from the initial guess (and one summary, so that no lazily loaded code
     # object is first touched inside the timed region), then reset: the timed region is exactly
@@ -128,9 +142,7 @@ def main():
     summ = summary()
     barrier()
     el = time.perf_counter() - t0
-    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = all_reduce(torch.tensor([el], dtype=torch.float64, device=dev), dist.ReduceOp.MAX)
     el = float(tmax.item())
 
     # per-kernel durations from the HIP events (this rank)
