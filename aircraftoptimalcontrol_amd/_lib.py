@@ -9,7 +9,7 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("AOC_LIB") or os.path.join(_PKG, "lib", "libaoc_hip.so")  # AOC_LIB: experiment builds
-_SRC = [os.path.join(_PKG, "csrc", f) for f in ("aoc_kernels.hip", "aoc_device.h")]
+_SRC = [os.path.join(_PKG, "csrc", f) for f in ("aoc_kernels.hip", "aoc_device.h", "aoc_passes.inc")]
 _HDR = os.path.join(os.path.dirname(_PKG), "include", "aoc.h")
 
 AOC_TILE = 64
@@ -81,6 +81,11 @@ SYMBOLS = {
     "aoc_ltv_lqr": (C.c_int, [_I, _I, _I] + [_P] * 17),
     "aoc_workspace_bytes": (_Z, [_I, _I]),
     "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 12),
+    "aoc_traj_cost_f32": (C.c_int, [_P] * 5),
+    "aoc_initial_trajectory_f32": (C.c_int, [_P, _D, _D, _P, _P, _P]),
+    "aoc_rollout_cost_f32": (C.c_int, [_P] * 9),
+    "aoc_workspace_bytes_f32": (_Z, [_I, _I]),
+    "aoc_newton_iterate_f32": (C.c_int, [_P, _P, _I] + [_P] * 12),
 }
 
 _lib = None

@@ -520,3 +520,83 @@ def ltv_lqr_batch(AA, BB, QQ, RR, SS, QQf, x0, qq=None, rr=None, qqf=None, devic
                             _ptr(r), _ptr(qf), _ptr(KK), _ptr(PP), _ptr(xx), _ptr(uu), _ptr(nreg), _ptr(nsing), st),
           "aoc_ltv_lqr")
     return tuple(t.cpu().numpy() for t in (KK, PP, xx, uu, nreg, nsing))
+
+
+
+class NewtonBatchSolverF32:
+    """The batched Newton iteration in float32 arithmetic (BASELINE configs[2]): every array float32,
+    every operation float32 (`aoc_*_f32`).  Not the parity path — the reference computes in fp64 —
+    but the same algorithm; used to measure how much accuracy float32 costs (tests/test_gpu_f32.py).
+    Interface: the subset of NewtonBatchSolver needed for fixed-iteration runs."""
+
+    def __init__(self, problem, B, params=None):
+        torch = _torch()
+        self.problem, self.B, self.T = problem, int(B), problem.T
+        self.params = params if params is not None else make_params()
+        dev = problem.device
+        self.nt = ntiles(self.B)
+        self.Bp = self.nt * TILE
+        f32 = torch.float32
+        self.ref32 = problem.ref.to(f32).contiguous()
+        self.xb = [alloc_tiled(B, self.T, 6, dev, zero=True, f32=True) for _ in range(2)]
+        self.ub = [alloc_tiled(B, self.T, 2, dev, zero=True, f32=True) for _ in range(2)]
+        self.ws = torch.empty((lib().aoc_workspace_bytes_f32(self.B, self.T) + 3) // 4, dtype=f32, device=dev)
+        f = lambda: torch.zeros(self.Bp, dtype=f32, device=dev)
+        self.J = [f(), f()]
+        self.descent, self.stepsize = f(), f()
+        self.ntrials = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
+        self.status = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
+        self.x0 = torch.zeros((self.nt, 6, TILE), dtype=f32, device=dev)
+        self.cur = self.jcur = self.kk = 0
+
+    def _p(self):
+        p = self.problem.c_problem(self.B, x_in_f32=1, x_out_f32=1)
+        p.ref = self.ref32.data_ptr()
+        return p
+
+    def set_initial_rollout(self, x0, uu):
+        """x0 (B,6), uu (B,2,T): the initial iterate is the open-loop rollout of uu from x0 (config 3:
+        warm start from a saved optimum)."""
+        torch = _torch()
+        dev = self.problem.device
+        self.x0.copy_(pack_vec(x0, dev).to(torch.float32))
+        ut = pack(uu, dev, f32=True)
+        p = self._p()
+        check(lib().aoc_rollout_cost_f32(C.byref(p), _ptr(self.x0), _ptr(ut), None, None, _ptr(self.xb[0]),
+                                         _ptr(self.ub[0]), _ptr(self.J[0]), _ptr(self.status)), "aoc_rollout_cost_f32")
+        self.cur = self.jcur = self.kk = 0
+
+    def set_initial_from_x0(self, x0, kp=5.0, kt=2.5):
+        torch = _torch()
+        dev = self.problem.device
+        self.x0.copy_(pack_vec(x0, dev).to(torch.float32))
+        p = self._p()
+        check(lib().aoc_initial_trajectory_f32(C.byref(p), float(kp), float(kt), _ptr(self.x0), _ptr(self.xb[0]),
+                                               _ptr(self.ub[0])), "aoc_initial_trajectory_f32")
+        check(lib().aoc_traj_cost_f32(C.byref(p), _ptr(self.xb[0]), _ptr(self.ub[0]), _ptr(self.x0), _ptr(self.J[0])),
+              "aoc_traj_cost_f32")
+        self.cur = self.jcur = self.kk = 0
+
+    def iterate(self, kk=None):
+        if kk is None:
+            kk = self.kk
+        p = self._p()
+        c, n = self.cur, 1 - self.cur
+        jc, jn = self.jcur, 1 - self.jcur
+        check(lib().aoc_newton_iterate_f32(C.byref(p), C.byref(self.params), int(kk), _ptr(self.xb[c]), _ptr(self.ub[c]),
+                                           _ptr(self.x0), _ptr(self.J[jc]), _ptr(self.ws), _ptr(self.xb[n]),
+                                           _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.descent), _ptr(self.stepsize),
+                                           _ptr(self.ntrials), _ptr(self.status)), "aoc_newton_iterate_f32")
+        self.cur, self.jcur, self.kk = n, jn, kk + 1
+
+    def current(self):
+        xx = unpack(self.xb[self.cur], self.B)
+        xx[:, :, 0] = unpack_vec(self.x0, self.B).to(xx.dtype)
+        return xx.cpu().numpy(), unpack(self.ub[self.cur], self.B).cpu().numpy()
+
+    def scalars(self):
+        B = self.B
+        g = lambda t: t[:B].double().cpu().numpy()
+        return dict(cost=g(self.J[1 - self.jcur]), descent=g(self.descent), stepsize=g(self.stepsize),
+                    ntrials=self.ntrials[:B].cpu().numpy(), cost_new=g(self.J[self.jcur]),
+                    status=self.status[:B].cpu().numpy())

@@ -9,23 +9,36 @@
 //   Dynamics.step            aircraft_simplified.py:263-393  (x+ rounded to float32: :300)
 //   Cost.stagecost/termcost  aircraft_simplified.py:25-97
 //   ltv_LQR (augmented)      optcon.py:655-751  in the equivalent 6-dim affine form, see lqr_stage()
-#pragma once
+// This header is included once per arithmetic type: AOC_ARITH_NS names the namespace, AOC_REAL the type
+// (double: the parity path; float: BASELINE config 3, "fp32 arithmetic everywhere").
 #include <hip/hip_runtime.h>
 
-namespace aoc {
+#if !defined(AOC_ARITH_NS) || !defined(AOC_REAL)
+#error "define AOC_ARITH_NS and AOC_REAL before including aoc_device.h"
+#endif
 
+#ifndef AOC_DEVICE_COMMON
+#define AOC_DEVICE_COMMON
+namespace aoc_common {
 constexpr int TILE = 64;
+}
+#endif
+
+namespace AOC_ARITH_NS {
+using aoc_common::TILE;
+typedef AOC_REAL real;
+#define R(x) ((real)(x))
 
 // Uniform (wave-invariant) constants: live in SGPRs / scalar loads from the kernarg segment.
 struct KConst {
     // model (aircraft_simplified.py:108-118) and derived uniform values
-    double cd0, cda, cla, m, g, S, rho, J, dt;
-    double dtm;    // dt/m
-    double mg;     // m*g
-    double hrho;   // 0.5*rho
-    double krs;    // rho*S
-    double b41;    // dt/J
-    double Q[36], R[4], QT[36];
+    real cd0, cda, cla, m, g, S, rho, J, dt;
+    real dtm;    // dt/m
+    real mg;     // m*g
+    real hrho;   // 0.5*rho
+    real krs;    // rho*S
+    real b41;    // dt/J
+    real Q[36], R[4], QT[36];
     int T, ntiles, B, diag;  // diag: Q,R,QT all diagonal (every driver of the reference)
 };
 
@@ -42,13 +55,13 @@ __device__ __forceinline__ size_t tix(int tile, int T, int t, int c, int lane) {
 // cost.  Written with contraction OFF and in the reference's association order so that a rollout
 // is bit-identical to NumPy's given identical sin/cos values.
 // ---------------------------------------------------------------------------------------------
-struct SC { double sg, cg, sa, ca; };
+struct SC { real sg, cg, sa, ca; };
 
-// sin and cos of one argument, branch-free for |x| < 2^20 (flight-path and attack angles are O(1)):
-// Cody-Waite reduction by pi/2 with three fused steps, then the classic minimax kernels on
+// sin and cos of one argument.  fp64: branch-free for |x| < 2^20 (flight-path and attack angles are
+// O(1)): Cody-Waite reduction by pi/2 with three fused steps, then the classic minimax kernels on
 // [-pi/4, pi/4] (degree 13 / 14, < 1 ulp).  The library sincos() spends ~150 instructions per call,
 // mostly on a Payne-Hanek path these arguments never take; this one is ~45 and has no control flow,
-// so the two calls per stage interleave.  Larger or non-finite arguments fall back to the library.
+// so the two calls per stage interleave.  float32 arithmetic (config 3) uses the library's sincosf.
 __device__ __forceinline__ void sincos_fast(double x, double* sp, double* cp) {
     const double n = __builtin_rint(x * 6.36619772367581382433e-01);          // x * 2/pi
     double r = __builtin_fma(-n, 1.57079632679489655800e+00, x);               // pi/2, exact step
@@ -79,43 +92,46 @@ __device__ __forceinline__ void sincos_fast(double x, double* sp, double* cp) {
     *sp = s;
     *cp = c;
 }
+__device__ __forceinline__ void sincos_fast(float x, float* sp, float* cp) { sincosf(x, sp, cp); }
+__device__ __forceinline__ void sincos_lib(double x, double* sp, double* cp) { sincos(x, sp, cp); }
+__device__ __forceinline__ void sincos_lib(float x, float* sp, float* cp) { sincosf(x, sp, cp); }
 
 // Both angle pairs of a stage.  The two fast evaluations are independent straight-line code (they
 // interleave); ONE rarely-taken branch afterwards redoes them with the library for huge or
 // non-finite arguments.
-__device__ __forceinline__ SC trig(double th, double ga) {
+__device__ __forceinline__ SC trig(real th, real ga) {
     SC s;
-    const double al = th - ga;
+    const real al = th - ga;
     sincos_fast(ga, &s.sg, &s.cg);
     sincos_fast(al, &s.sa, &s.ca);
-    if (!(__builtin_fabs(ga) < 1048576.0 && __builtin_fabs(al) < 1048576.0)) {
-        sincos(ga, &s.sg, &s.cg);
-        sincos(al, &s.sa, &s.ca);
+    if (!(__builtin_fabs(ga) < R(1048576.0) && __builtin_fabs(al) < R(1048576.0))) {
+        sincos_lib(ga, &s.sg, &s.cg);
+        sincos_lib(al, &s.sa, &s.ca);
     }
     return s;
 }
 
 #pragma clang fp contract(off)
-__device__ __forceinline__ void step_state(const KConst& k, const double x[6], double u0, double u1,
-                                           const SC& s, double xp[6]) {
-    const double V = x[2], al = x[3] - x[5];
-    const double V2 = V * V;
-    const double D = k.hrho * V2 * k.S * (k.cd0 + k.cda * (al * al));   // aircraft_simplified.py:228
-    const double L = k.hrho * V2 * k.S * k.cla * al;                    // :253
-    xp[0] = (double)(float)(x[0] + k.dt * V * s.cg);                    // :303
-    xp[1] = (double)(float)(x[1] - k.dt * V * s.sg);                    // :304
-    xp[2] = (double)(float)(V + k.dtm * (-D - k.mg * s.sg + u0 * s.ca)); // :306
-    xp[3] = (double)(float)(x[3] + k.dt * x[4]);                        // :307
-    xp[4] = (double)(float)(x[4] + k.dt * (u1 / k.J));                  // :309
-    xp[5] = (double)(float)(x[5] + (k.dt / (k.m * V)) * (L - k.mg * s.cg + u0 * s.sa)); // :310
+__device__ __forceinline__ void step_state(const KConst& k, const real x[6], real u0, real u1,
+                                           const SC& s, real xp[6]) {
+    const real V = x[2], al = x[3] - x[5];
+    const real V2 = V * V;
+    const real D = k.hrho * V2 * k.S * (k.cd0 + k.cda * (al * al));   // aircraft_simplified.py:228
+    const real L = k.hrho * V2 * k.S * k.cla * al;                    // :253
+    xp[0] = (real)(float)(x[0] + k.dt * V * s.cg);                    // :303
+    xp[1] = (real)(float)(x[1] - k.dt * V * s.sg);                    // :304
+    xp[2] = (real)(float)(V + k.dtm * (-D - k.mg * s.sg + u0 * s.ca)); // :306
+    xp[3] = (real)(float)(x[3] + k.dt * x[4]);                        // :307
+    xp[4] = (real)(float)(x[4] + k.dt * (u1 / k.J));                  // :309
+    xp[5] = (real)(float)(x[5] + (k.dt / (k.m * V)) * (L - k.mg * s.cg + u0 * s.sa)); // :310
 }
 
 // l(x,u) = (0.5 dx)^T (Q dx) + (0.5 du)^T (R du)   (aircraft_simplified.py:61), ascending sums.
 // Also returns q = Q dx, r = R du (lx, lu at :63-64).
 template <bool DIAG>
-__device__ __forceinline__ double stage_cost(const KConst& k, const double x[6], double u0, double u1,
-                                             const double* __restrict__ ref, double q[6], double r[2]) {
-    double dx[6], du[2];
+__device__ __forceinline__ real stage_cost(const KConst& k, const real x[6], real u0, real u1,
+                                             const real* __restrict__ ref, real q[6], real r[2]) {
+    real dx[6], du[2];
 #pragma unroll
     for (int i = 0; i < 6; i++) dx[i] = x[i] - ref[i];
     du[0] = u0 - ref[6];
@@ -128,42 +144,42 @@ __device__ __forceinline__ double stage_cost(const KConst& k, const double x[6],
     } else {
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            double a = 0.0;
+            real a = R(0.0);
 #pragma unroll
             for (int j = 0; j < 6; j++) a += k.Q[i * 6 + j] * dx[j];
             q[i] = a;
         }
-        r[0] = (0.0 + k.R[0] * du[0]) + k.R[1] * du[1];
-        r[1] = (0.0 + k.R[2] * du[0]) + k.R[3] * du[1];
+        r[0] = (R(0.0) + k.R[0] * du[0]) + k.R[1] * du[1];
+        r[1] = (R(0.0) + k.R[2] * du[0]) + k.R[3] * du[1];
     }
-    double a = 0.0, b = 0.0;
+    real a = R(0.0), b = R(0.0);
 #pragma unroll
-    for (int i = 0; i < 6; i++) a += (0.5 * dx[i]) * q[i];
-    b += (0.5 * du[0]) * r[0];
-    b += (0.5 * du[1]) * r[1];
+    for (int i = 0; i < 6; i++) a += (R(0.5) * dx[i]) * q[i];
+    b += (R(0.5) * du[0]) * r[0];
+    b += (R(0.5) * du[1]) * r[1];
     return a + b;
 }
 
 // l_T(x) = ((0.5 dx)^T Q_T) dx, q_f = Q_T dx   (aircraft_simplified.py:92-94)
 template <bool DIAG>
-__device__ __forceinline__ double term_cost(const KConst& k, const double x[6],
-                                            const double* __restrict__ ref, double qf[6]) {
-    double dx[6], v[6];
+__device__ __forceinline__ real term_cost(const KConst& k, const real x[6],
+                                            const real* __restrict__ ref, real qf[6]) {
+    real dx[6], v[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) dx[i] = x[i] - ref[i];
     if (DIAG) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) { v[i] = (0.5 * dx[i]) * k.QT[i * 6 + i]; qf[i] = k.QT[i * 6 + i] * dx[i]; }
+        for (int i = 0; i < 6; i++) { v[i] = (R(0.5) * dx[i]) * k.QT[i * 6 + i]; qf[i] = k.QT[i * 6 + i] * dx[i]; }
     } else {
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            double a = 0.0, c = 0.0;
+            real a = R(0.0), c = R(0.0);
 #pragma unroll
-            for (int i = 0; i < 6; i++) { a += (0.5 * dx[i]) * k.QT[i * 6 + j]; c += k.QT[j * 6 + i] * dx[i]; }
+            for (int i = 0; i < 6; i++) { a += (R(0.5) * dx[i]) * k.QT[i * 6 + j]; c += k.QT[j * 6 + i] * dx[i]; }
             v[j] = a; qf[j] = c;
         }
     }
-    double ll = 0.0;
+    real ll = R(0.0);
 #pragma unroll
     for (int j = 0; j < 6; j++) ll += v[j] * dx[j];
     return ll;
@@ -175,30 +191,30 @@ __device__ __forceinline__ double term_cost(const KConst& k, const double x[6],
 // Non-constant entries only; A00=A11=A33=A44=1, A34=dt, B41=dt/J.
 // ---------------------------------------------------------------------------------------------
 struct Lin {
-    double a02, a05, a12, a15, a22, a23, a25, a52, a53, a55;
-    double b20, b50;
+    real a02, a05, a12, a15, a22, a23, a25, a52, a53, a55;
+    real b20, b50;
 };
 
-__device__ __forceinline__ Lin linearise(const KConst& k, const double x[6], double u0, const SC& s) {
+__device__ __forceinline__ Lin linearise(const KConst& k, const real x[6], real u0, const SC& s) {
     Lin l;
-    const double V = x[2], al = x[3] - x[5], V2 = V * V;
-    const double iV = 1.0 / V;
-    const double dtmV = k.dtm * iV;                     // dt/(m V)
+    const real V = x[2], al = x[3] - x[5], V2 = V * V;
+    const real iV = R(1.0) / V;
+    const real dtmV = k.dtm * iV;                     // dt/(m V)
     l.a02 = k.dt * s.cg;
     l.a05 = -k.dt * V * s.sg;
     l.a12 = -k.dt * s.sg;
     l.a15 = -k.dt * V * s.cg;
-    const double cdt = k.cd0 + k.cda * al * al;
-    l.a22 = 1.0 - k.dtm * (k.krs * V * cdt);
-    const double dA = k.cda * k.krs * al * V2 + u0 * s.sa;     // (Cda S rho 2 al V^2)/2 + u0 sin(al)
+    const real cdt = k.cd0 + k.cda * al * al;
+    l.a22 = R(1.0) - k.dtm * (k.krs * V * cdt);
+    const real dA = k.cda * k.krs * al * V2 + u0 * s.sa;     // (Cda S rho 2 al V^2)/2 + u0 sin(al)
     l.a23 = -k.dtm * dA;
     l.a25 = k.dtm * (dA - k.mg * s.cg);
-    const double hl = 0.5 * k.cla * k.krs * V2;                // Cla S rho V^2 / 2
-    const double lA = hl * al + u0 * s.sa - k.mg * s.cg;
+    const real hl = R(0.5) * k.cla * k.krs * V2;                // Cla S rho V^2 / 2
+    const real lA = hl * al + u0 * s.sa - k.mg * s.cg;
     l.a52 = k.dtm * (k.cla * k.krs * al) - dtmV * iV * lA;
-    const double lB = hl + u0 * s.ca;
+    const real lB = hl + u0 * s.ca;
     l.a53 = dtmV * lB;
-    l.a55 = 1.0 - dtmV * (lB - k.mg * s.sg);
+    l.a55 = R(1.0) - dtmV * (lB - k.mg * s.sg);
     l.b20 = k.dtm * s.ca;
     l.b50 = dtmV * s.sa;
     return l;
@@ -208,36 +224,36 @@ __device__ __forceinline__ Lin linearise(const KConst& k, const double x[6], dou
 // 6x6  sum_k lam_k d2f_k/dx2  has six distinct non-zeros, the 2x6  sum_k lam_k d2f_k/dudx  three
 // (row 0 only); d2f/du2 == 0.
 struct Hess {
-    double h22, h23, h25, h33, h35, h55;  // fxx
-    double s02, s03, s05;                 // fux row 0
+    real h22, h23, h25, h33, h35, h55;  // fxx
+    real s02, s03, s05;                 // fux row 0
 };
 
-__device__ __forceinline__ Hess hessian(const KConst& k, const double x[6], double u0, const SC& s,
-                                        const double lam[6]) {
+__device__ __forceinline__ Hess hessian(const KConst& k, const real x[6], real u0, const SC& s,
+                                        const real lam[6]) {
     Hess h;
-    const double V = x[2], al = x[3] - x[5], V2 = V * V;
-    const double iV = 1.0 / V, iV2 = iV * iV;
-    const double dtmV = k.dtm * iV, dtmV2 = k.dtm * iV2;
-    const double l0 = lam[0], l1 = lam[1], l2 = lam[2], l5 = lam[5];
+    const real V = x[2], al = x[3] - x[5], V2 = V * V;
+    const real iV = R(1.0) / V, iV2 = iV * iV;
+    const real dtmV = k.dtm * iV, dtmV2 = k.dtm * iV2;
+    const real l0 = lam[0], l1 = lam[1], l2 = lam[2], l5 = lam[5];
     // k = 0, 1  (:339-352)
-    const double f0_25 = -k.dt * s.sg, f0_55 = -k.dt * V * s.cg;
-    const double f1_25 = -k.dt * s.cg, f1_55 = k.dt * V * s.sg;
+    const real f0_25 = -k.dt * s.sg, f0_55 = -k.dt * V * s.cg;
+    const real f1_25 = -k.dt * s.cg, f1_55 = k.dt * V * s.sg;
     // k = 2  (:354-359)
-    const double f2_22 = -k.dtm * (k.krs * (k.cd0 + k.cda * al * al));
-    const double f2_23 = -k.dtm * (k.cda * k.krs * V * (2.0 * al));
-    const double e2 = k.cda * k.krs * V2 + u0 * s.ca;
-    const double f2_33 = -k.dtm * e2;
-    const double f2_55 = -k.dtm * (e2 - k.mg * s.sg);
+    const real f2_22 = -k.dtm * (k.krs * (k.cd0 + k.cda * al * al));
+    const real f2_23 = -k.dtm * (k.cda * k.krs * V * (R(2.0) * al));
+    const real e2 = k.cda * k.krs * V2 + u0 * s.ca;
+    const real f2_33 = -k.dtm * e2;
+    const real f2_55 = -k.dtm * (e2 - k.mg * s.sg);
     // k = 5  (:361-366)
-    const double hl = 0.5 * k.cla * k.krs * V2;
-    const double lA = hl * al + u0 * s.sa - k.mg * s.cg;
-    const double cl = k.cla * k.krs * k.dtm;                    // Cla S dt rho / m
-    const double f5_22 = 2.0 * dtmV2 * iV * lA - cl * al * iV;
-    const double lB = hl + u0 * s.ca;
-    const double f5_23 = cl - dtmV2 * lB;
-    const double f5_25 = dtmV2 * (lB - k.mg * s.sg) - cl;
-    const double f5_33 = -dtmV * (u0 * s.sa);
-    const double f5_55 = -dtmV * (u0 * s.sa - k.mg * s.cg);
+    const real hl = R(0.5) * k.cla * k.krs * V2;
+    const real lA = hl * al + u0 * s.sa - k.mg * s.cg;
+    const real cl = k.cla * k.krs * k.dtm;                    // Cla S dt rho / m
+    const real f5_22 = R(2.0) * dtmV2 * iV * lA - cl * al * iV;
+    const real lB = hl + u0 * s.ca;
+    const real f5_23 = cl - dtmV2 * lB;
+    const real f5_25 = dtmV2 * (lB - k.mg * s.sg) - cl;
+    const real f5_33 = -dtmV * (u0 * s.sa);
+    const real f5_55 = -dtmV * (u0 * s.sa - k.mg * s.cg);
     h.h22 = l2 * f2_22 + l5 * f5_22;
     h.h23 = l2 * f2_23 + l5 * f5_23;
     h.h25 = l0 * f0_25 + l1 * f1_25 - l2 * f2_23 + l5 * f5_25;
@@ -245,8 +261,8 @@ __device__ __forceinline__ Hess hessian(const KConst& k, const double x[6], doub
     h.h35 = -l2 * f2_33 - l5 * f5_33;
     h.h55 = l0 * f0_55 + l1 * f1_55 + l2 * f2_55 + l5 * f5_55;
     // fux (:375-379)
-    const double g2_03 = -k.dtm * s.sa;
-    const double g5_02 = -dtmV2 * s.sa, g5_03 = dtmV * s.ca;
+    const real g2_03 = -k.dtm * s.sa;
+    const real g5_02 = -dtmV2 * s.sa, g5_03 = dtmV * s.ca;
     h.s02 = l5 * g5_02;
     h.s03 = l2 * g2_03 + l5 * g5_03;
     h.s05 = -l2 * g2_03 - l5 * g5_03;
@@ -254,7 +270,7 @@ __device__ __forceinline__ Hess hessian(const KConst& k, const double x[6], doub
 }
 
 // y = A^T v  (sparse)
-__device__ __forceinline__ void At_vec(const KConst& k, const Lin& l, const double v[6], double y[6]) {
+__device__ __forceinline__ void At_vec(const KConst& k, const Lin& l, const real v[6], real y[6]) {
     y[0] = v[0];
     y[1] = v[1];
     y[2] = l.a02 * v[0] + l.a12 * v[1] + l.a22 * v[2] + l.a52 * v[5];
@@ -264,7 +280,7 @@ __device__ __forceinline__ void At_vec(const KConst& k, const Lin& l, const doub
 }
 
 // y = A v  (sparse)
-__device__ __forceinline__ void A_vec(const KConst& k, const Lin& l, const double v[6], double y[6]) {
+__device__ __forceinline__ void A_vec(const KConst& k, const Lin& l, const real v[6], real y[6]) {
     y[0] = v[0] + l.a02 * v[2] + l.a05 * v[5];
     y[1] = v[1] + l.a12 * v[2] + l.a15 * v[5];
     y[2] = l.a22 * v[2] + l.a23 * v[3] + l.a25 * v[5];
@@ -294,41 +310,41 @@ __host__ __device__ constexpr int sidx(int i, int j) { return i * 6 - (i * (i - 
 // ---------------------------------------------------------------------------------------------
 struct StageFlags { bool singular, regularised; };
 
-__device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, double P[21], double p[6],
-                                                const double Qs[21], double s02, double s03, double s05,
-                                                const double hq[6], const double hr[2], double Kt[14]) {
+__device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, real P[21], real p[6],
+                                                const real Qs[21], real s02, real s03, real s05,
+                                                const real hq[6], const real hr[2], real Kt[14]) {
     // M = R + B^T P B  (2x2, symmetric), from the six entries of P that B touches
-    const double P22 = P[sidx(2, 2)], P24 = P[sidx(2, 4)], P25 = P[sidx(2, 5)], P44 = P[sidx(4, 4)],
+    const real P22 = P[sidx(2, 2)], P24 = P[sidx(2, 4)], P25 = P[sidx(2, 5)], P44 = P[sidx(4, 4)],
                  P45 = P[sidx(4, 5)], P55 = P[sidx(5, 5)];
-    const double bp2 = l.b20 * P22 + l.b50 * P25;   // (B^T P)[0,2]
-    const double bp5 = l.b20 * P25 + l.b50 * P55;   // (B^T P)[0,5]
-    const double bp4 = l.b20 * P24 + l.b50 * P45;   // (B^T P)[0,4]
-    const double M00 = k.R[0] + (bp2 * l.b20 + bp5 * l.b50);
-    const double M01 = k.R[1] + bp4 * k.b41;
-    const double M11 = k.R[3] + (k.b41 * P44) * k.b41;
+    const real bp2 = l.b20 * P22 + l.b50 * P25;   // (B^T P)[0,2]
+    const real bp5 = l.b20 * P25 + l.b50 * P55;   // (B^T P)[0,5]
+    const real bp4 = l.b20 * P24 + l.b50 * P45;   // (B^T P)[0,4]
+    const real M00 = k.R[0] + (bp2 * l.b20 + bp5 * l.b50);
+    const real M01 = k.R[1] + bp4 * k.b41;
+    const real M11 = k.R[3] + (k.b41 * P44) * k.b41;
     StageFlags fl;
-    const double det = M00 * M11 - M01 * M01;
-    fl.singular = (det == 0.0);
-    const double idet = 1.0 / det;
-    const double i00 = M11 * idet, i01 = -M01 * idet, i11 = M00 * idet;
+    const real det = M00 * M11 - M01 * M01;
+    fl.singular = (det == R(0.0));
+    const real idet = R(1.0) / det;
+    const real i00 = M11 * idet, i01 = -M01 * idet, i11 = M00 * idet;
     // M positive definite <=> tr > 0 and det > 0 (equivalent to all(eigvals(M) > 0), optcon.py:745)
-    const bool pd = (M00 + M11 > 0.0) && (det > 0.0);
+    const bool pd = (M00 + M11 > R(0.0)) && (det > R(0.0));
     fl.regularised = !pd;
     // affine column: h = B^T p + r/2, M^-1 h
-    const double h0 = l.b20 * p[2] + l.b50 * p[5] + hr[0];
-    const double h1 = k.b41 * p[4] + hr[1];
-    const double mh0 = i00 * h0 + i01 * h1, mh1 = i01 * h0 + i11 * h1;
+    const real h0 = l.b20 * p[2] + l.b50 * p[5] + hr[0];
+    const real h1 = k.b41 * p[4] + hr[1];
+    const real mh0 = i00 * h0 + i01 * h1, mh1 = i01 * h0 + i11 * h1;
     Kt[0] = -mh0; Kt[7] = -mh1;
     // Column by column: W[:,j] = (P A)[:,j], G[:,j] = (B^T W)[:,j] + S[:,j], M^-1 G[:,j],
     // z = (A^T W)[:,j], P_t[i,j] = Q[i,j] + z[i] - G[:,i]^T M^-1 G[:,j] for i <= j.  Only one column of W
     // is alive at a time; the new P is built beside the old one.
-    double Pn[21], G0[6], G1[6];
+    real Pn[21], G0[6], G1[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-        double w[6];
+        real w[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            const double pi0 = SYM(P, i, 0), pi1 = SYM(P, i, 1), pi2 = SYM(P, i, 2), pi3 = SYM(P, i, 3),
+            const real pi0 = SYM(P, i, 0), pi1 = SYM(P, i, 1), pi2 = SYM(P, i, 2), pi3 = SYM(P, i, 3),
                          pi4 = SYM(P, i, 4), pi5 = SYM(P, i, 5);
             w[i] = j == 0 ? pi0
                  : j == 1 ? pi1
@@ -337,15 +353,15 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, d
                  : j == 4 ? pi3 * k.dt + pi4
                           : pi0 * l.a05 + pi1 * l.a15 + pi2 * l.a25 + pi5 * l.a55;
         }
-        double g0 = l.b20 * w[2] + l.b50 * w[5];
-        const double g1 = k.b41 * w[4];
+        real g0 = l.b20 * w[2] + l.b50 * w[5];
+        const real g1 = k.b41 * w[4];
         if (j == 2) g0 += s02;
         if (j == 3) g0 += s03;
         if (j == 5) g0 += s05;
         G0[j] = g0; G1[j] = g1;
-        const double mg0 = i00 * g0 + i01 * g1, mg1 = i01 * g0 + i11 * g1;
+        const real mg0 = i00 * g0 + i01 * g1, mg1 = i01 * g0 + i11 * g1;
         Kt[1 + j] = -mg0; Kt[8 + j] = -mg1;
-        const double z[6] = {w[0], w[1],
+        const real z[6] = {w[0], w[1],
                              l.a02 * w[0] + l.a12 * w[1] + l.a22 * w[2] + l.a52 * w[5],
                              l.a23 * w[2] + w[3] + l.a53 * w[5],
                              k.dt * w[3] + w[4],
@@ -354,11 +370,11 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, d
         for (int i = 0; i <= j; i++) Pn[sidx(i, j)] = Qs[sidx(i, j)] + z[i] - (G0[i] * mg0 + G1[i] * mg1);
     }
     if (!pd) {  // gains from the regularised M + 0.5 I (optcon.py:745-751); the Riccati update above keeps M (Q3)
-        const double r00 = M00 + 0.5, r11 = M11 + 0.5;
-        const double rdet = r00 * r11 - M01 * M01;
-        if (rdet == 0.0) fl.singular = true;
-        const double ird = 1.0 / rdet;
-        const double j00 = r11 * ird, j01 = -M01 * ird, j11 = r00 * ird;
+        const real r00 = M00 + R(0.5), r11 = M11 + R(0.5);
+        const real rdet = r00 * r11 - M01 * M01;
+        if (rdet == R(0.0)) fl.singular = true;
+        const real ird = R(1.0) / rdet;
+        const real j00 = r11 * ird, j01 = -M01 * ird, j11 = r00 * ird;
         Kt[0] = -(j00 * h0 + j01 * h1); Kt[7] = -(j01 * h0 + j11 * h1);
 #pragma unroll
         for (int j = 0; j < 6; j++) {
@@ -367,7 +383,7 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, d
         }
     }
     // p_t = q/2 + A^T p - G^T (M^-1 h)
-    double ap[6];
+    real ap[6];
     At_vec(k, l, p, ap);
 #pragma unroll
     for (int i = 0; i < 6; i++) p[i] = hq[i] + ap[i] - (G0[i] * mh0 + G1[i] * mh1);
@@ -376,4 +392,5 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, d
     return fl;
 }
 
-}  // namespace aoc
+#undef SYM
+}  // namespace AOC_ARITH_NS

@@ -83,7 +83,8 @@ typedef struct aoc_problem {
     int32_t T;        /* samples per trajectory = int(tf/dt), optcon.py:378 (T-1 stages) */
     int32_t x_in_f32; /* element type of the tiled STATE arrays a call reads: 0 = fp64, 1 = float32 */
     int32_t x_out_f32;/* ... and of those it writes (see "State storage" above) */
-    const double *ref;/* DEVICE, shared by the batch, time-major [T][8]: xx_ref[0..5,t], uu_ref[0..1,t] */
+    const void *ref;  /* DEVICE, shared by the batch, time-major [T][8]: xx_ref[0..5,t], uu_ref[0..1,t]; fp64
+                       (float32 for the *_f32 entry points) */
     void *stream;     /* hipStream_t */
 } aoc_problem;
 
@@ -223,6 +224,25 @@ int aoc_newton_iterate(const aoc_problem *prob, const aoc_params *prm, int32_t k
                        const double *u, const double *x0, const double *J_cur, void *workspace,
                        void *x_new, double *u_new, double *J_new, double *descent, double *stepsize,
                        int32_t *ntrials, int32_t *status);
+
+/* ---------------------------------------------------------------------------------------------
+ * float32 arithmetic (BASELINE.json configs[2]: "fp32 with tolerance sweep").
+ * The same kernels compiled with float as the arithmetic type: EVERY array (states, inputs, gains,
+ * costs, per-trajectory scalars, x0, the reference curves `prob->ref`, the workspace) is float32 and
+ * every operation is a float32 operation; aoc_problem/aoc_params keep their fp64 fields and are
+ * converted once on the host.  prob->x_in_f32 / x_out_f32 are ignored.  Semantics otherwise as the
+ * fp64 entry point of the same name.  This variant is NOT the parity path: the reference computes in
+ * fp64; tests/test_gpu_f32.py reports how far the float32 iterates drift from the fp64 ones.
+ * --------------------------------------------------------------------------------------------- */
+int aoc_traj_cost_f32(const aoc_problem *prob, const float *x, const float *u, const float *x0, float *J);
+int aoc_initial_trajectory_f32(const aoc_problem *prob, double kp, double kt, const float *x0, float *x, float *u);
+int aoc_rollout_cost_f32(const aoc_problem *prob, const float *x0, const float *u, const float *du,
+                         const float *alpha, float *x_out, float *u_out, float *J_out, int32_t *status);
+size_t aoc_workspace_bytes_f32(int32_t B, int32_t T);
+int aoc_newton_iterate_f32(const aoc_problem *prob, const aoc_params *prm, int32_t kk, const float *x,
+                           const float *u, const float *x0, const float *J_cur, void *workspace,
+                           float *x_new, float *u_new, float *J_new, float *descent, float *stepsize,
+                           int32_t *ntrials, int32_t *status);
 
 #ifdef __cplusplus
 }
