@@ -18,7 +18,16 @@ def run(B=65536, seed=20260402, iters=(1, 2, 5, 10)):
     XI, UI, J0, _ = batch.rollout_cost(bp, x0, uu0)
     s64 = batch.NewtonBatchSolver(bp, B, prm); s64.set_initial(XI, UI)
     s32 = batch.NewtonBatchSolverF32(bp, B, prm); s32.set_initial_rollout(x0, uu0)
+    import torch, time
     out = {}
+    # throughput of the two arithmetic types on this workload (10 iterations each, then reset)
+    for name, sv in (("f64", s64), ("f32", s32)):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for k in range(10):
+            sv.iterate(k)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out["ms_per_iteration_" + name] = dt / 10 * 1e3
+    s64.set_initial(XI, UI); s32.set_initial_rollout(x0, uu0)
     for k in range(max(iters)):
         s64.iterate(k); s32.iterate(k)
         if k + 1 in iters:
