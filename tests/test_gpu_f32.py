@@ -2,7 +2,7 @@
 started from the reference's saved optimum (Data/uu_star_acrobatic.npy), against the fp64 path.
 float32 is not the parity path (the reference computes in fp64); this test pins what it costs:
 costs agree to ~1e-6 relative, inputs to ~1e-3 (gains of ~1e3 amplify the 6e-8 rounding), and the
-sweep over tolerances is written to gpurun_out/f32_sweep.json (full-size run: scratch/f32_sweep.py)."""
+sweep over tolerances is written to gpurun_out/f32_sweep.json (full-size run: tools/f32_sweep.py)."""
 import json
 import os
 import sys
@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_f32_tolerance_sweep_acrobatic():
-    sys.path.insert(0, os.path.join(ROOT, "scratch"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
     os.chdir(ROOT)
     import f32_sweep
     r = f32_sweep.run(B=1024, iters=(1, 2, 5))

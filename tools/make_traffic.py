@@ -1,4 +1,4 @@
-"""profiles/<tag>_* from a gpurun_out/<tag> directory produced by scratch/profile_round.sh, and
+"""profiles/<tag>_* from a gpurun_out/<tag> directory produced by tools/profile_round.sh, and
 profiles/traffic.json (what bench.py reports as roofline.traffic)."""
 import json, shutil, sys, os
 tag = sys.argv[1]; name = sys.argv[2] if len(sys.argv) > 2 else tag
