@@ -51,7 +51,9 @@ def cpu_baseline(pr, x0, iters):
     from oracle import oracle as orc
     op = orc.OracleProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     prm = orc.params(stepsize_0=1.0, armijo_maxiters=10)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # threads: the CPU share of a one-GPU box is 16 cores, whatever the number of visible CPUs
+    vis = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(vis, int(os.environ.get("AOC_CPU_THREADS", "16"))))
     # calibrate on 4 trajectories per core, then size the sample for ~15 s of wall time
     nb = min(4 * cores, x0.shape[0])
     XI, UI = problems.initial_guess_batch(pr, x0[:nb])

@@ -25,6 +25,36 @@
 
 #define NS 6
 #define NI 2
+
+/* Scratch arrays of one call come from a per-thread arena (chunks are kept and reused): with
+ * calloc/free per call the batched driver spends its time in the allocator and in page faults once
+ * many threads run, which would understate the CPU baseline. */
+#define ARENA_CHUNKS 64
+typedef struct { char *base[ARENA_CHUNKS]; size_t cap[ARENA_CHUNKS]; int n, cur; size_t top; } orc_arena;
+static _Thread_local orc_arena g_arena;
+typedef struct { int cur; size_t top; } orc_mark;
+
+static orc_mark arena_mark(void) { orc_mark m = {g_arena.cur, g_arena.top}; return m; }
+static void arena_release(orc_mark m) { g_arena.cur = m.cur; g_arena.top = m.top; }
+static void *arena_calloc(size_t n, size_t sz) {
+    orc_arena *a = &g_arena;
+    size_t bytes = (n * sz + 63) & ~(size_t)63;
+    for (;;) {
+        if (a->cur < a->n && a->top + bytes <= a->cap[a->cur]) {
+            void *p = a->base[a->cur] + a->top;
+            a->top += bytes;
+            memset(p, 0, bytes);
+            return p;
+        }
+        if (a->cur + 1 < a->n) { a->cur++; a->top = 0; continue; }
+        if (a->n == ARENA_CHUNKS) return calloc(n, sz); /* never in practice; leaks by design */
+        size_t cap = bytes > ((size_t)4 << 20) ? bytes : ((size_t)4 << 20);
+        a->base[a->n] = (char *)malloc(cap);
+        a->cap[a->n] = cap;
+        a->cur = a->n++;
+        a->top = 0;
+    }
+}
 #define NA 7 /* augmented state dimension ns+1 (optcon.py:657-666) */
 
 typedef struct {
@@ -288,15 +318,16 @@ int orc_ltv_lqr(int T, const double *AAin, const double *BBin, const double *QQi
                 const double *SSin, const double *QQfin, const double *x0, const double *qq,
                 const double *rr, const double *qqf, double *KK, double *PPout, double *xxout,
                 double *uuout, int *nreg) {
+    const orc_mark mark_ = arena_mark();
     const int aug = (qq != NULL) || (rr != NULL) || (qqf != NULL); /* :614 */
     const int n = aug ? NA : NS;
     int nsing = 0, reg = 0;
-    double *PP = (double *)calloc((size_t)T * n * n, sizeof(double));
-    double *AA = (double *)calloc((size_t)T * n * n, sizeof(double));
-    double *BB = (double *)calloc((size_t)T * n * 2, sizeof(double));
-    double *QQ = (double *)calloc((size_t)T * n * n, sizeof(double));
-    double *SS = (double *)calloc((size_t)T * 2 * n, sizeof(double));
-    double *xx = (double *)calloc((size_t)T * n, sizeof(double));
+    double *PP = (double *)arena_calloc((size_t)T * n * n, sizeof(double));
+    double *AA = (double *)arena_calloc((size_t)T * n * n, sizeof(double));
+    double *BB = (double *)arena_calloc((size_t)T * n * 2, sizeof(double));
+    double *QQ = (double *)arena_calloc((size_t)T * n * n, sizeof(double));
+    double *SS = (double *)arena_calloc((size_t)T * 2 * n, sizeof(double));
+    double *xx = (double *)arena_calloc((size_t)T * n, sizeof(double));
     double QQf[NA * NA];
     memset(QQf, 0, sizeof QQf);
     memset(KK, 0, (size_t)T * 2 * n * sizeof(double));
@@ -388,7 +419,7 @@ int orc_ltv_lqr(int T, const double *AAin, const double *BBin, const double *QQi
         for (int i = 0; i < 6; i++) xxout[t * 6 + i] = xx[(size_t)t * n + (aug ? 1 : 0) + i];
     if (PPout) memcpy(PPout, PP, (size_t)T * n * n * sizeof(double));
     if (nreg) *nreg = reg;
-    free(PP); free(AA); free(BB); free(QQ); free(SS); free(xx);
+    arena_release(mark_);
     return nsing;
 }
 
@@ -449,21 +480,22 @@ int orc_newton_iterate(const orc_problem *p, const orc_params *prm, int kk, cons
                        const double *uu, const double *x0, double *xx_new, double *uu_new,
                        double *JJ_out, double *descent_out, double *stepsize_out, int *ntrials_out,
                        int *nreg_out, double *KK_out, double *du_out, double *dx_out, double *lmbd_out) {
+    const orc_mark mark_ = arena_mark();
     const int T = p->T;
-    double *AA = (double *)calloc((size_t)T * 36, sizeof(double));
-    double *BB = (double *)calloc((size_t)T * 12, sizeof(double));
-    double *QQ = (double *)calloc((size_t)T * 36, sizeof(double));
-    double *RR = (double *)calloc((size_t)T * 4, sizeof(double));
-    double *SS = (double *)calloc((size_t)T * 12, sizeof(double));
-    double *qq = (double *)calloc((size_t)T * 6, sizeof(double));
-    double *rr = (double *)calloc((size_t)T * 2, sizeof(double));
-    double *lm = (double *)calloc((size_t)T * 6, sizeof(double));
-    double *KK = (double *)calloc((size_t)T * 14, sizeof(double));
-    double *dxl = (double *)calloc((size_t)T * 6, sizeof(double));
-    double *dul = (double *)calloc((size_t)T * 2, sizeof(double));
-    double *du = (double *)calloc((size_t)T * 2, sizeof(double));
-    double *wx = (double *)calloc((size_t)T * 6, sizeof(double));
-    double *wu = (double *)calloc((size_t)T * 2, sizeof(double));
+    double *AA = (double *)arena_calloc((size_t)T * 36, sizeof(double));
+    double *BB = (double *)arena_calloc((size_t)T * 12, sizeof(double));
+    double *QQ = (double *)arena_calloc((size_t)T * 36, sizeof(double));
+    double *RR = (double *)arena_calloc((size_t)T * 4, sizeof(double));
+    double *SS = (double *)arena_calloc((size_t)T * 12, sizeof(double));
+    double *qq = (double *)arena_calloc((size_t)T * 6, sizeof(double));
+    double *rr = (double *)arena_calloc((size_t)T * 2, sizeof(double));
+    double *lm = (double *)arena_calloc((size_t)T * 6, sizeof(double));
+    double *KK = (double *)arena_calloc((size_t)T * 14, sizeof(double));
+    double *dxl = (double *)arena_calloc((size_t)T * 6, sizeof(double));
+    double *dul = (double *)arena_calloc((size_t)T * 2, sizeof(double));
+    double *du = (double *)arena_calloc((size_t)T * 2, sizeof(double));
+    double *wx = (double *)arena_calloc((size_t)T * 6, sizeof(double));
+    double *wu = (double *)arena_calloc((size_t)T * 2, sizeof(double));
     double x[6], u[2], xr[6], ur[2], a[6], b[2], fx[36], fu[12], fxx[36], fuu[4], fux[12];
 
     double JJ = orc_traj_cost(p, xx, uu);                                  /* A  :417-424 */
@@ -524,8 +556,7 @@ int orc_newton_iterate(const orc_problem *p, const orc_params *prm, int kk, cons
     if (du_out) memcpy(du_out, du, (size_t)T * 2 * sizeof(double));
     if (dx_out) for (int t = 0; t < T; t++) for (int c = 0; c < 6; c++) dx_out[c * T + t] = dxl[t * 6 + c];
     if (lmbd_out) for (int t = 0; t < T; t++) for (int c = 0; c < 6; c++) lmbd_out[c * T + t] = lm[t * 6 + c];
-    free(AA); free(BB); free(QQ); free(RR); free(SS); free(qq); free(rr); free(lm); free(KK);
-    free(dxl); free(dul); free(du); free(wx); free(wu);
+    arena_release(mark_);
     return nsing;
 }
 
@@ -597,14 +628,15 @@ void orc_initial_trajectory(const orc_model *md, int T, const double *xx_ref, do
 int orc_lqr_tracking(const orc_model *md, int T, const double *QQt, const double *RRt, const double *QQT,
                      const double *xx_opt, const double *uu_opt, const double *delta, double *xx_reg,
                      double *uu_reg, double *KK_out) {
-    double *AA = (double *)calloc((size_t)T * 36, sizeof(double));
-    double *BB = (double *)calloc((size_t)T * 12, sizeof(double));
-    double *QQ = (double *)calloc((size_t)T * 36, sizeof(double));
-    double *RR = (double *)calloc((size_t)T * 4, sizeof(double));
-    double *SS = (double *)calloc((size_t)T * 12, sizeof(double));
-    double *KK = (double *)calloc((size_t)T * 12, sizeof(double));
-    double *lx = (double *)calloc((size_t)T * 6, sizeof(double));
-    double *lu = (double *)calloc((size_t)T * 2, sizeof(double));
+    const orc_mark mark_ = arena_mark();
+    double *AA = (double *)arena_calloc((size_t)T * 36, sizeof(double));
+    double *BB = (double *)arena_calloc((size_t)T * 12, sizeof(double));
+    double *QQ = (double *)arena_calloc((size_t)T * 36, sizeof(double));
+    double *RR = (double *)arena_calloc((size_t)T * 4, sizeof(double));
+    double *SS = (double *)arena_calloc((size_t)T * 12, sizeof(double));
+    double *KK = (double *)arena_calloc((size_t)T * 12, sizeof(double));
+    double *lx = (double *)arena_calloc((size_t)T * 6, sizeof(double));
+    double *lu = (double *)arena_calloc((size_t)T * 2, sizeof(double));
     double x[6], u[2], xn[6], fx[36], fu[12];
     for (int t = 0; t < T; t++) { /* :268-273 */
         for (int c = 0; c < 6; c++) x[c] = xx_opt[c * T + t];
@@ -631,7 +663,7 @@ int orc_lqr_tracking(const orc_model *md, int T, const double *QQt, const double
         for (int c = 0; c < 6; c++) { x[c] = xn[c]; xx_reg[c * T + t + 1] = xn[c]; }
     }
     if (KK_out) memcpy(KK_out, KK, (size_t)T * 12 * sizeof(double));
-    free(AA); free(BB); free(QQ); free(RR); free(SS); free(KK); free(lx); free(lu);
+    arena_release(mark_);
     return nsing;
 }
 
