@@ -3,7 +3,7 @@ d = sys.argv[1]
 f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("aoc64::", "").replace("aoc32::", "f32::")
     res[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, dd in res.items():
     if not k.startswith("k_") or k.startswith("k_ls_plan") or k.startswith("k_ls_res") or k.startswith("k_ls_init"):

@@ -9,7 +9,7 @@ for kind in ("fetch", "write"):
     if not fs:
         continue
     for r in csv.DictReader(open(fs[0])):
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("aoc64::", "").replace("aoc32::", "f32::")
         res[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summ = {}
 for k, d in res.items():

@@ -5,7 +5,7 @@ rows.sort(key=lambda r:int(r['Start_Timestamp']))
 seq=[]
 for r in rows:
     n=r['Kernel_Name']; d=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
-    short=n.split('(')[0].replace('void ','')
+    short=n.split('(')[0].replace('void ','').replace('aoc64::','').replace('aoc32::','f32::')
     if short.startswith('k_'): seq.append((short,d,int(r['Start_Timestamp']),int(r['End_Timestamp']), r.get('VGPR_Count'), r.get('Grid_Size_X')))
 it=-1; out=collections.defaultdict(list)
 for s in seq:
