@@ -73,8 +73,8 @@ SYMBOLS = {
     "aoc_traj_cost": (C.c_int, [_P, _P, _P, _P, _P]),
     "aoc_initial_trajectory": (C.c_int, [_P, _D, _D, _P, _P, _P]),
     "aoc_rollout_cost": (C.c_int, [_P] * 9),
-    "aoc_backward": (C.c_int, [_P, _I] + [_P] * 7),
-    "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 9),
+    "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
+    "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 8),
     "aoc_linesearch_scratch_bytes": (_Z, [_I]),
     "aoc_linesearch": (C.c_int, [_P, _P, _I] + [_P] * 13),
     "aoc_lqr_tracking": (C.c_int, [_P] * 9),

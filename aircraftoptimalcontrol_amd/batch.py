@@ -282,18 +282,18 @@ class NewtonBatchSolver:
         jc, jn = self.jcur, 1 - self.jcur
         nel14 = lib().aoc_tiled_elems(self.B, self.T, 14)
         nel2 = lib().aoc_tiled_elems(self.B, self.T, 2)
-        Kt, g, du = self.ws[:nel14], self.ws[nel14:nel14 + nel2], self.ws[nel14 + nel2:nel14 + 2 * nel2]
+        Kt, du = self.ws[:nel14], self.ws[nel14:nel14 + nel2]
         nsp = self.n_spec
-        Jt = self.ws[nel14 + 2 * nel2:nel14 + 2 * nel2 + 3 * self.Bp]
-        scratch = self.ws[nel14 + 2 * nel2 + 3 * self.Bp:]
+        Jt = self.ws[nel14 + nel2:nel14 + nel2 + 3 * self.Bp]
+        scratch = self.ws[nel14 + nel2 + 3 * self.Bp:]
         st = torch.cuda.current_stream(self.problem.device)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record(st)
         check(lib().aoc_backward(C.byref(p), int(kk > prm.hessian_switch), _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
-                                 _ptr(Kt), _ptr(g), None, _ptr(self.status)), "aoc_backward")
+                                 _ptr(Kt), None, _ptr(self.status)), "aoc_backward")
         ev[1].record(st)
         check(lib().aoc_forward(C.byref(p), C.byref(prm), nsp, _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
-                                _ptr(Kt), _ptr(g), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status)),
+                                _ptr(Kt), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status)),
               "aoc_forward")
         ev[2].record(st)
         check(lib().aoc_linesearch(C.byref(p), C.byref(prm), nsp, _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
@@ -448,7 +448,7 @@ def rollout_cost(problem, x0, uu, du=None, alpha=None, write=True, f32=False):
 
 def backward_forward(problem, xx, uu, full_hessian, stepsize_0=1.0, f32=False):
     """One backward + forward pass (reference optcon.py:429-477 and the first Armijo trial).
-    Returns dict with K~ (B,2,7,T), g (B,2,T), du (B,2,T), descent (B,), lmbd0 (B,6), J_trial0, status.
+    Returns dict with K~ (B,2,7,T), du (B,2,T), descent (B,), lmbd0 (B,6), J_trial0, status.
     f32: hand the state trajectory over as float32 (requires float32-valued samples t >= 1)."""
     torch = _torch()
     dev = problem.device
@@ -457,7 +457,6 @@ def backward_forward(problem, xx, uu, full_hessian, stepsize_0=1.0, f32=False):
     nt = ntiles(B)
     xt, ut = pack(xx, dev, f32=f32), pack(uu, dev)
     Kt = alloc_tiled(B, T, 14, dev, zero=True)
-    g = alloc_tiled(B, T, 2, dev, zero=True)
     du = alloc_tiled(B, T, 2, dev)
     lm0 = torch.empty((nt, 6, TILE), dtype=torch.float64, device=dev)
     desc = torch.empty(nt * TILE, dtype=torch.float64, device=dev)
@@ -465,13 +464,13 @@ def backward_forward(problem, xx, uu, full_hessian, stepsize_0=1.0, f32=False):
     st = torch.zeros(nt * TILE, dtype=torch.int32, device=dev)
     x0t = pack_vec(xx[:, :, 0], dev)
     p = problem.c_problem(B, x_in_f32=int(f32))
-    check(lib().aoc_backward(C.byref(p), int(bool(full_hessian)), _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(g),
+    check(lib().aoc_backward(C.byref(p), int(bool(full_hessian)), _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt),
                              _ptr(lm0), _ptr(st)), "aoc_backward")
     prm = make_params(stepsize_0=stepsize_0)
-    check(lib().aoc_forward(C.byref(p), C.byref(prm), 1, _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(g), _ptr(du),
+    check(lib().aoc_forward(C.byref(p), C.byref(prm), 1, _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(du),
                             _ptr(desc), _ptr(Jn), _ptr(st)), "aoc_forward")
     KK = unpack(Kt, B).cpu().numpy().reshape(B, 2, 7, T)
-    return dict(KK=KK, g=unpack(g, B).cpu().numpy(), du=unpack(du, B).cpu().numpy(),
+    return dict(KK=KK, du=unpack(du, B).cpu().numpy(),
                 descent=desc[:B].cpu().numpy(), lmbd0=unpack_vec(lm0, B).cpu().numpy(),
                 J_trial0=Jn[:B].cpu().numpy(), status=st[:B].cpu().numpy())
 

@@ -185,13 +185,12 @@ int aoc_rollout_cost(const aoc_problem* p, const double* x0, const double* u, co
     return aoc64::api_rollout_cost(p, x0, u, du, alpha, x_out, u_out, J_out, status);
 }
 int aoc_backward(const aoc_problem* p, int32_t full_hessian, const void* x, const double* u, const double* x0,
-                 double* Kt, double* g, double* lmbd0, int32_t* status) {
-    return aoc64::api_backward(p, full_hessian, x, u, x0, Kt, g, lmbd0, status);
+                 double* Kt, double* lmbd0, int32_t* status) {
+    return aoc64::api_backward(p, full_hessian, x, u, x0, Kt, lmbd0, status);
 }
 int aoc_forward(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const void* x, const double* u,
-                const double* x0, const double* Kt, const double* g, double* du, double* descent, double* J_trial,
-                int32_t* status) {
-    return aoc64::api_forward(p, prm, n_spec, x, u, x0, Kt, g, du, descent, J_trial, status);
+                const double* x0, const double* Kt, double* du, double* descent, double* J_trial, int32_t* status) {
+    return aoc64::api_forward(p, prm, n_spec, x, u, x0, Kt, du, descent, J_trial, status);
 }
 int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const double* u, const double* x0,
                    const double* du, const double* J_cur, const double* descent, const double* J_trial, void* x_new,

@@ -30,7 +30,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes per trajectory and stage: fp64 elements x 8
-ALGO_BYTES = {"backward": (8 + 16) * 8, "forward": (24 + 2) * 8, "linesearch": (4 + 8) * 8, "iteration": 496}
+# per kernel: fp64 elements the kernel's formulation moves; "iteration": SURVEY 8d's figure for a whole
+# Newton iteration (its formulation also carries g = B^T lambda + r, 2 elements written and read)
+ALGO_BYTES = {"backward": (8 + 14) * 8, "forward": (22 + 2) * 8, "linesearch": (4 + 8) * 8, "iteration": 496}
 
 
 def parse():

@@ -153,24 +153,27 @@ int aoc_initial_trajectory(const aoc_problem *prob, double kp, double kt, const 
 int aoc_rollout_cost(const aoc_problem *prob, const double *x0, const double *u, const double *du,
                      const double *alpha, void *x_out, double *u_out, double *J_out, int32_t *status);
 
-/* Backward pass of one Newton iteration: terminal condition, costate sweep, quadratisation
- * (Gauss-Newton or full Hessian) and the affine Riccati/gain recursion of ltv_LQR, fused
- * (optcon.py:429-464 + :655-751).  Writes per stage the gain K~ (2x7: column 0 feed-forward sigma,
- * columns 1..6 feedback K) as 14 components and g = B^T lambda_{t+1} + r (2 components).
- * Kt: tiled C=14 over T samples (sample T-1 unused), g: tiled C=2.
- * lmbd0 (optional, [ntiles][6][64]) receives lambda_0. */
+/* Backward pass of one Newton iteration: terminal condition, quadratisation (Gauss-Newton, or full
+ * Hessian with the costate sweep lambda_t = A^T lambda_{t+1} + l_x, optcon.py:461) and the affine
+ * Riccati/gain recursion of ltv_LQR, fused (optcon.py:429-464 + :655-751).  Writes per stage the gain
+ * K~ (2x7: column 0 feed-forward sigma, columns 1..6 feedback K) as 14 components.
+ * Kt: tiled C=14 over T samples (sample T-1 unused).
+ * lmbd0 (optional, [ntiles][6][64]) receives lambda_0 (forces the costate sweep). */
 int aoc_backward(const aoc_problem *prob, int32_t full_hessian, const void *x, const double *u,
-                 const double *x0, double *Kt, double *g, double *lmbd0, int32_t *status);
+                 const double *x0, double *Kt, double *lmbd0, int32_t *status);
 
-/* Forward pass: closed-loop linear rollout of ltv_LQR (optcon.py:756-762) giving du, the descent
- * sum (optcon.py:474-477), fused with the first n_spec (1..3) Armijo trials: for step
- * alpha_j = stepsize_0*beta^j, u' = u + alpha_j*du, nonlinear rollout x' from x0, cost J'_j
- * (optcon.py:250-264).  The pass is bound by the K~ stream, so trials 1.. ride along for free; the
- * reference evaluates them one after the other, the verdict order is kept by aoc_linesearch.
+/* Forward pass: closed-loop linear rollout of ltv_LQR (optcon.py:756-762) giving du; the descent
+ *   sum_t (B_t^T lambda_{t+1} + r_t)^T du_t   (optcon.py:474-477)
+ * evaluated through the adjoint identity  sum_t (q_t^T dx_t + r_t^T du_t) + q_f^T dx_{T-1}  (same number,
+ * 1e-13 relative on the golden cases; the costate then never leaves the backward pass); fused with
+ * the first n_spec (1..3) Armijo trials: for step alpha_j = stepsize_0*beta^j, u' = u + alpha_j*du,
+ * nonlinear rollout x' from x0, cost J'_j (optcon.py:250-264).  The trials ride along with the K~
+ * stream; the reference evaluates them one after the other, the verdict order is kept by
+ * aoc_linesearch.
  * Outputs: du (tiled C=2), descent[ntiles*64], J_trial[n_spec][ntiles*64]. */
 int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const void *x, const double *u,
-                const double *x0, const double *Kt, const double *g, double *du, double *descent,
-                double *J_trial, int32_t *status);
+                const double *x0, const double *Kt, double *du, double *descent, double *J_trial,
+                int32_t *status);
 
 /* Armijo back-tracking (optcon.py:243-273) and the final update (optcon.py:488-491).
  * Trial ii uses alpha_ii = stepsize_0*beta^ii and is accepted iff J'(alpha_ii) <= J_cur +
