@@ -43,7 +43,6 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=131072)
     ap.add_argument("--horizon", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="trajectories in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
 
 
