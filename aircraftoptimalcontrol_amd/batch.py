@@ -177,7 +177,7 @@ class NewtonBatchSolver:
 
     Device state (tiled): three (x,u) iterate buffers in rotation — states as float32 (lossless: every
     propagated state of the reference is a float32 value, aircraft_simplified.py:300; sample 0 lives in
-    the fp64 x0 array), inputs as fp64 — the K~/g/du workspace and per-trajectory scalars.  A
+    the fp64 x0 array), inputs as fp64 — the K~/du workspace and per-trajectory scalars.  A
     caller-supplied initial iterate whose samples are not float32 values is kept in an extra fp64
     buffer and read from there by the first iteration.  `iterate(kk)` = one outer iteration for every
     trajectory; `solve()` adds the reference's termination and return-index behaviour per trajectory."""
