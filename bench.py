@@ -195,7 +195,11 @@ def main():
         "status_or_rank0": int(np.bitwise_or.reduce(sc["status"])),
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pr, x0, min(a.steps, 10))
+        try:
+            out["cpu_baseline"] = cpu_baseline(pr, x0, min(a.steps, 10))
+        except Exception as e:  # the baseline is a report, never a reason to lose the bench line
+            out["cpu_baseline"] = None
+            out["cpu_baseline_error"] = repr(e)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
