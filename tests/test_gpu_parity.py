@@ -406,3 +406,29 @@ def test_initial_iterate_with_arbitrary_fp64_samples(aoc):
     r2 = s2.solve()
     # descent >= -1e30 at kk = 0 already: index -1 = the all-zero slot (Q7)
     assert r2["iters"].tolist() == [1, 1] and not r2["xx_star"].any() and not r2["uu_star"].any()
+
+
+def test_solve_returns_initial_iterate_when_stopping_at_kk1(aoc):
+    """Q7 at its edge: a trajectory whose descent passes the threshold at kk = 1 returns history index 0,
+    i.e. the caller's initial iterate itself (with uu[:,-1] = uu[:,-2], Q8) — also when that iterate is
+    not float32-valued and lives in the fp64 side buffer."""
+    g, bp, op = _problem(aoc, "problem_step_T500")
+    c = load_golden("g6_chain_step_T500")
+    d0, d1 = c["descent"][0], c["descent"][1]
+    assert d0 < d1 < 0
+    thr = 0.5 * (d0 + d1)                      # descent[0] < thr <= descent[1]
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10, term_cond=thr)
+    s = aoc.NewtonBatchSolver(bp, 1, prm)
+    s.set_initial(c["xx_init"][None], c["uu_init"][None])
+    r = s.solve()
+    assert r["iters"][0] == 2 and r["converged"][0]
+    assert np.array_equal(r["xx_star"][0], c["xx_init"])
+    exp_u = c["uu_init"].copy(); exp_u[:, -1] = exp_u[:, -2]
+    assert np.array_equal(r["uu_star"][0], exp_u)
+    # same with an initial iterate that is not float32-representable
+    xx0 = c["xx_init"].copy(); xx0[:, 1:] += 1e-9
+    s.set_initial(xx0[None], c["uu_init"][None])
+    assert s.cur_is64
+    r = s.solve()
+    if r["iters"][0] == 2:
+        assert np.array_equal(r["xx_star"][0], xx0)
