@@ -96,12 +96,39 @@ __device__ __forceinline__ void sincos_fast(float x, float* sp, float* cp) { sin
 __device__ __forceinline__ void sincos_lib(double x, double* sp, double* cp) { sincos(x, sp, cp); }
 __device__ __forceinline__ void sincos_lib(float x, float* sp, float* cp) { sincosf(x, sp, cp); }
 
-// Both angle pairs of a stage.  The two fast evaluations are independent straight-line code (they
-// interleave); ONE rarely-taken branch afterwards redoes them with the library for huge or
-// non-finite arguments.
+// The two minimax kernels alone, for |r| <= pi/4 (no reduction, no quadrant logic).
+__device__ __forceinline__ void sincos_kernel(double r, double* sp, double* cp) {
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    *sp = __builtin_fma(r * z, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    *cp = w + (((1.0 - w) - hz) + (z * z) * pc);
+}
+__device__ __forceinline__ void sincos_kernel(float r, float* sp, float* cp) { sincosf(r, sp, cp); }
+
+// Both angle pairs of a stage.  Flight-path angle and angle of attack are almost always inside
+// [-pi/4, pi/4], where the reduction step is the identity (n = 0, r = x exactly) and the quadrant
+// selection passes the kernels through: when that holds for the whole wavefront the kernels are
+// evaluated directly — same bits, a dozen instructions fewer per angle.  Otherwise the general
+// branch-free path; ONE rarely-taken branch redoes huge or non-finite arguments with the library.
 __device__ __forceinline__ SC trig(real th, real ga) {
     SC s;
     const real al = th - ga;
+    const real qp = R(0.78);  // < pi/4: rint(x * 2/pi) == 0 on [-qp, qp]
+    if (__all(__builtin_fabs(ga) <= qp && __builtin_fabs(al) <= qp)) {
+        sincos_kernel(ga, &s.sg, &s.cg);
+        sincos_kernel(al, &s.sa, &s.ca);
+        return s;
+    }
     sincos_fast(ga, &s.sg, &s.cg);
     sincos_fast(al, &s.sa, &s.ca);
     if (!(__builtin_fabs(ga) < R(1048576.0) && __builtin_fabs(al) < R(1048576.0))) {
@@ -126,11 +153,15 @@ __device__ __forceinline__ void step_state(const KConst& k, const real x[6], rea
     xp[5] = (real)(float)(x[5] + (k.dt / (k.m * V)) * (L - k.mg * s.cg + u0 * s.sa)); // :310
 }
 
-// l(x,u) = (0.5 dx)^T (Q dx) + (0.5 du)^T (R du)   (aircraft_simplified.py:61), ascending sums.
-// Also returns q = Q dx, r = R du (lx, lu at :63-64).
+// Stage and terminal cost.  The reference evaluates l = (0.5 dx)^T (Q dx) + (0.5 du)^T (R du)
+// (aircraft_simplified.py:61) and sums l over the horizon (optcon.py:417-424).  Multiplying by 0.5 is
+// exact and commutes with every rounding of the products and sums involved (no under/overflow at
+// these magnitudes), so the functions below return 2l, the callers accumulate 2J in the same order
+// and halve ONCE at the end: bit-identical to the reference's J, eight multiplications fewer per stage.
+// q = Q dx, r = R du are lx, lu (:63-64).
 template <bool DIAG>
-__device__ __forceinline__ real stage_cost(const KConst& k, const real x[6], real u0, real u1,
-                                             const real* __restrict__ ref, real q[6], real r[2]) {
+__device__ __forceinline__ real stage_cost2(const KConst& k, const real x[6], real u0, real u1,
+                                            const real* __restrict__ ref, real q[6], real r[2]) {
     real dx[6], du[2];
 #pragma unroll
     for (int i = 0; i < 6; i++) dx[i] = x[i] - ref[i];
@@ -154,28 +185,28 @@ __device__ __forceinline__ real stage_cost(const KConst& k, const real x[6], rea
     }
     real a = R(0.0), b = R(0.0);
 #pragma unroll
-    for (int i = 0; i < 6; i++) a += (R(0.5) * dx[i]) * q[i];
-    b += (R(0.5) * du[0]) * r[0];
-    b += (R(0.5) * du[1]) * r[1];
+    for (int i = 0; i < 6; i++) a += dx[i] * q[i];
+    b += du[0] * r[0];
+    b += du[1] * r[1];
     return a + b;
 }
 
-// l_T(x) = ((0.5 dx)^T Q_T) dx, q_f = Q_T dx   (aircraft_simplified.py:92-94)
+// 2 l_T(x) = (dx^T Q_T) dx, q_f = Q_T dx   (aircraft_simplified.py:92-94)
 template <bool DIAG>
-__device__ __forceinline__ real term_cost(const KConst& k, const real x[6],
-                                            const real* __restrict__ ref, real qf[6]) {
+__device__ __forceinline__ real term_cost2(const KConst& k, const real x[6],
+                                           const real* __restrict__ ref, real qf[6]) {
     real dx[6], v[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) dx[i] = x[i] - ref[i];
     if (DIAG) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) { v[i] = (R(0.5) * dx[i]) * k.QT[i * 6 + i]; qf[i] = k.QT[i * 6 + i] * dx[i]; }
+        for (int i = 0; i < 6; i++) { v[i] = dx[i] * k.QT[i * 6 + i]; qf[i] = k.QT[i * 6 + i] * dx[i]; }
     } else {
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             real a = R(0.0), c = R(0.0);
 #pragma unroll
-            for (int i = 0; i < 6; i++) { a += (R(0.5) * dx[i]) * k.QT[i * 6 + j]; c += k.QT[j * 6 + i] * dx[i]; }
+            for (int i = 0; i < 6; i++) { a += dx[i] * k.QT[i * 6 + j]; c += k.QT[j * 6 + i] * dx[i]; }
             v[j] = a; qf[j] = c;
         }
     }
