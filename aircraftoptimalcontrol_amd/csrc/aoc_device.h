@@ -96,39 +96,13 @@ __device__ __forceinline__ void sincos_fast(float x, float* sp, float* cp) { sin
 __device__ __forceinline__ void sincos_lib(double x, double* sp, double* cp) { sincos(x, sp, cp); }
 __device__ __forceinline__ void sincos_lib(float x, float* sp, float* cp) { sincosf(x, sp, cp); }
 
-// The two minimax kernels alone, for |r| <= pi/4 (no reduction, no quadrant logic).
-__device__ __forceinline__ void sincos_kernel(double r, double* sp, double* cp) {
-    const double z = r * r;
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
-    *sp = __builtin_fma(r * z, ps, r);
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
-    const double hz = 0.5 * z, w = 1.0 - hz;
-    *cp = w + (((1.0 - w) - hz) + (z * z) * pc);
-}
-__device__ __forceinline__ void sincos_kernel(float r, float* sp, float* cp) { sincosf(r, sp, cp); }
-
-// Both angle pairs of a stage.  Flight-path angle and angle of attack are almost always inside
-// [-pi/4, pi/4], where the reduction step is the identity (n = 0, r = x exactly) and the quadrant
-// selection passes the kernels through: when that holds for the whole wavefront the kernels are
-// evaluated directly — same bits, a dozen instructions fewer per angle.  Otherwise the general
-// branch-free path; ONE rarely-taken branch redoes huge or non-finite arguments with the library.
+// Both angle pairs of a stage.  The two fast evaluations are independent straight-line code (they
+// interleave); ONE rarely-taken branch afterwards redoes them with the library for huge or
+// non-finite arguments.  (A wave-uniform shortcut for |angle| <= pi/4, where the reduction is the
+// identity, was measured and bought nothing: the extra branch costs what the dozen instructions save.)
 __device__ __forceinline__ SC trig(real th, real ga) {
     SC s;
     const real al = th - ga;
-    const real qp = R(0.78);  // < pi/4: rint(x * 2/pi) == 0 on [-qp, qp]
-    if (__all(__builtin_fabs(ga) <= qp && __builtin_fabs(al) <= qp)) {
-        sincos_kernel(ga, &s.sg, &s.cg);
-        sincos_kernel(al, &s.sa, &s.ca);
-        return s;
-    }
     sincos_fast(ga, &s.sg, &s.cg);
     sincos_fast(al, &s.sa, &s.ca);
     if (!(__builtin_fabs(ga) < R(1048576.0) && __builtin_fabs(al) < R(1048576.0))) {
