@@ -9,9 +9,9 @@ thrust to an integer because its result vector aliases an int array (aircraft_si
 uue = [46, 0].  The solver output is a one-off set-up value, captured here as constants
 (SciPy 1.15.3) instead of re-running SciPy.
 
-Input generators for the batched configs (perturbed / random x0, P-controller initial guess) are
-host-side NumPy, vectorised over the batch: they produce the synthetic inputs, they are not part of
-the accelerated path.
+Input generators for the batched configs (perturbed / random x0) are host-side NumPy: they produce the
+synthetic start states; the P-controller initial guess itself is rolled out on the device
+(`aoc_initial_trajectory`, `NewtonBatchSolver.set_initial_from_x0`).
 """
 from dataclasses import dataclass
 
@@ -135,43 +135,3 @@ def random_x0(B, seed=20260403, first=0):
         out[b:b + n] = lo + (hi - lo) * u[off:off + n]
         b += n
     return out
-
-
-def step_f64_f32(x, u, dt):
-    """Vectorised x+ = f(x,u) with float32 rounding of the result (aircraft_simplified.py:303-310).
-    x (B,6), u (B,2)."""
-    m, g, J = MODEL["m"], MODEL["g"], MODEL["J"]
-    rho, S, cd0, cda, cla = MODEL["rho"], MODEL["S"], MODEL["cd0"], MODEL["cda"], MODEL["cla"]
-    V, th, q, ga = x[:, 2], x[:, 3], x[:, 4], x[:, 5]
-    al = th - ga
-    D = 0.5 * rho * V ** 2 * S * (cd0 + cda * al ** 2)
-    L = 0.5 * rho * V ** 2 * S * cla * al
-    xp = np.empty_like(x)
-    xp[:, 0] = x[:, 0] + dt * V * np.cos(ga)
-    xp[:, 1] = x[:, 1] - dt * V * np.sin(ga)
-    xp[:, 2] = V + (dt / m) * (-D - m * g * np.sin(ga) + u[:, 0] * np.cos(al))
-    xp[:, 3] = th + dt * q
-    xp[:, 4] = q + dt * (u[:, 1] / J)
-    xp[:, 5] = ga + (dt / (m * V)) * (L - m * g * np.cos(ga) + u[:, 0] * np.sin(al))
-    return xp.astype(np.float32).astype(np.float64)
-
-
-def initial_guess_batch(pr, x0):
-    """P-controller initial guess of Dynamics.get_initial_trajectory (aircraft_simplified.py:134-147,
-    kp = 5, kt = 2.5) rolled from every x0_b.  fp64 arithmetic + float32 state rounding; the
-    reference's own version runs mostly in float32 under NumPy-2 promotion, so the two agree to
-    ~1e-4, which is irrelevant for an initial guess.  Returns (B,6,T), (B,2,T)."""
-    B, T = x0.shape[0], pr.T
-    xx = np.zeros((B, 6, T))
-    uu = np.zeros((B, 2, T))
-    x = np.array(x0, dtype=np.float64)
-    xx[:, :, 0] = x
-    xr = pr.xx_ref
-    u = np.zeros((B, 2))
-    for i in range(T - 1):
-        u[:, 0] = 5.0 * ((x[:, 0] - xr[0, i + 1]) + (x[:, 1] - xr[1, i + 1]))
-        u[:, 1] = 2.5 * ((x[:, 3] - xr[3, i + 1]) + (x[:, 5] - xr[5, i + 1]))
-        x = step_f64_f32(x, u, pr.dt)
-        xx[:, :, i + 1] = x
-        uu[:, :, i] = u
-    return xx, uu

@@ -48,7 +48,6 @@ def parse():
 
 def cpu_baseline(pr, x0, iters):
     """The oracle on this host's cores: a bounded sample of the same workload, same iterations."""
-    from aircraftoptimalcontrol_amd import problems
     from oracle import oracle as orc
     op = orc.OracleProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     prm = orc.params(stepsize_0=1.0, armijo_maxiters=10)
@@ -57,12 +56,13 @@ def cpu_baseline(pr, x0, iters):
     cores = max(1, min(vis, int(os.environ.get("AOC_CPU_THREADS", "16"))))
     # calibrate on 4 trajectories per core, then size the sample for ~15 s of wall time
     nb = min(4 * cores, x0.shape[0])
-    XI, UI = problems.initial_guess_batch(pr, x0[:nb])
+    mdl = orc.default_model(pr.dt)
+    XI, UI = orc.initial_guess_batch(mdl, pr.xx_ref, x0[:nb], nthreads=cores)
     t0 = time.time()
     orc.newton_iterate_batch(op, prm, XI, UI, XI[:, :, 0].copy(), 0, 1, nthreads=cores)
     rate = nb / max(time.time() - t0, 1e-4)          # trajectory-iterations per second
     n = int(min(x0.shape[0], 32768, max(cores, rate * 40.0 / iters)))
-    XI, UI = problems.initial_guess_batch(pr, x0[:n])
+    XI, UI = orc.initial_guess_batch(mdl, pr.xx_ref, x0[:n], nthreads=cores)
     t0 = time.time()
     orc.newton_iterate_batch(op, prm, XI, UI, XI[:, :, 0].copy(), 0, iters, nthreads=cores)
     dt = time.time() - t0

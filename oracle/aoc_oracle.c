@@ -699,6 +699,22 @@ int orc_newton_iterate_batch(const orc_problem *p, const orc_params *prm, int B,
     return nsing;
 }
 
+/* Initial guesses for a batch: the P-controller rollout from every x0[b] against the shared reference
+   (get_initial_trajectory with xx_ref[:,0] replaced by x0[b]). */
+void orc_initial_trajectory_batch(const orc_model *md, int B, int T, const double *xx_ref, const double *x0,
+                                  double *xx, double *uu, int nthreads) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+    for (int b = 0; b < B; b++) {
+        double *xr = (double *)malloc((size_t)6 * T * sizeof(double));
+        memcpy(xr, xx_ref, (size_t)6 * T * sizeof(double));
+        for (int c = 0; c < 6; c++) xr[c * T] = x0[(size_t)b * 6 + c];
+        orc_initial_trajectory(md, T, xr, xx + (size_t)b * 6 * T, uu + (size_t)b * 2 * T);
+        free(xr);
+    }
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
     extern int omp_get_max_threads(void);

@@ -183,6 +183,17 @@ def initial_trajectory(model, xx_ref):
     return xx, uu
 
 
+def initial_guess_batch(model, xx_ref, x0, nthreads=0):
+    """P-controller initial guesses from every x0[b] (B,6) against the shared xx_ref (6,T)."""
+    xr, x0 = _f64(xx_ref), _f64(x0)
+    B, T = x0.shape[0], xr.shape[1]
+    xx = np.zeros((B, 6, T)); uu = np.zeros((B, 2, T))
+    if nthreads <= 0:
+        nthreads = lib().orc_max_threads()
+    lib().orc_initial_trajectory_batch(C.byref(model), B, T, _p(xr), _p(x0), _p(xx), _p(uu), int(nthreads))
+    return xx, uu
+
+
 def lqr_tracking(model, QQt, RRt, QQT, xx_opt, uu_opt, delta):
     xo, uo = _f64(xx_opt), _f64(uu_opt); T = xo.shape[1]
     xr = np.zeros((6, T)); ur = np.zeros((2, T)); KK = np.zeros((T, 2, 6))

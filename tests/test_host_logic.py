@@ -37,10 +37,11 @@ def test_random_x0_is_keyed_by_global_index():
     assert np.all(full >= lo) and np.all(full <= hi)
 
 
-def test_initial_guess_batch_matches_reference_to_fp32_noise():
+def test_oracle_initial_guess_batch_matches_reference_to_fp32_noise():
+    from oracle import oracle as orc
     pr = problems.step_maneuver(1.0, 2e-3)
     g = load_golden("g9_minibatch_step_T500")
-    XI, UI = problems.initial_guess_batch(pr, g["x0"])
+    XI, UI = orc.initial_guess_batch(orc.default_model(pr.dt), pr.xx_ref, g["x0"], nthreads=2)
     assert np.abs(XI - g["xx_init"]).max() < 1e-4 and np.abs(UI - g["uu_init"]).max() < 1e-3
     assert np.array_equal(XI[:, :, 0], g["x0"])
 
