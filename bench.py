@@ -61,7 +61,7 @@ def cpu_baseline(pr, x0, iters):
     t0 = time.time()
     orc.newton_iterate_batch(op, prm, XI, UI, XI[:, :, 0].copy(), 0, 1, nthreads=cores)
     rate = nb / max(time.time() - t0, 1e-4)          # trajectory-iterations per second
-    n = int(min(x0.shape[0], 32768, max(cores, rate * 40.0 / iters)))
+    n = int(min(x0.shape[0], 65536, max(cores, rate * 40.0 / iters)))
     XI, UI = orc.initial_guess_batch(mdl, pr.xx_ref, x0[:n], nthreads=cores)
     t0 = time.time()
     orc.newton_iterate_batch(op, prm, XI, UI, XI[:, :, 0].copy(), 0, iters, nthreads=cores)
