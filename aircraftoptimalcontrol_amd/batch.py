@@ -338,71 +338,122 @@ class NewtonBatchSolver:
                 hist.append(self.scalars())
         return hist
 
-    def solve(self, verbose=False, callback=None):
+    def _compacted(self, keep):
+        """A new solver holding only the trajectories `keep` (device index tensor into this one): their
+        current and previous iterate, x0, current cost and status."""
+        torch = _torch()
+        n, dev = self.B, self.problem.device
+        m = int(keep.numel())
+        nw = NewtonBatchSolver(self.problem, m, self.params)
+        nw.n_spec = self.n_spec
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for src, dst in (((self.cur - 1) % 3, 0), (self.cur, 1)):   # previous -> slot 0, current -> slot 1
+            xs = unpack(self.xb[src], n)[keep].contiguous()
+            us = unpack(self.ub[src], n)[keep].contiguous()
+            check(lib().aoc_pack_f32(m, self.T, 6, _ptr(xs), _ptr(nw.xb[dst]), st), "aoc_pack_f32")
+            check(lib().aoc_pack(m, self.T, 2, _ptr(us), _ptr(nw.ub[dst]), st), "aoc_pack")
+        nw.x0.copy_(pack_vec(unpack_vec(self.x0, n)[keep], dev))
+        nw.J[0][:m] = self.J[self.jcur][:n][keep]
+        nw.status[:m] = self.status[:n][keep]
+        if self.x_init is not None:
+            nw.x_init, nw.u_init = self.x_init[keep], self.u_init[keep]
+        nw.cur, nw.jcur, nw.kk, nw.cur_is64 = 1, 0, self.kk, False
+        return nw
+
+    def solve(self, verbose=False, callback=None, compact=True, compact_below=0.5, compact_min=2048):
         """NewtonMethod.optimize semantics per trajectory (reference optcon.py:415-505):
         iterate kk = 0..max_iters-2; a trajectory stops at the first kk with descent >= term_cond and
         then returns iterate kk-1 (python index -1 = an all-zero history slot when kk == 0); without
         convergence it returns the last computed iterate; finally uu_star[:,-1] = uu_star[:,-2].
-        Returns dict(xx_star (B,6,T), uu_star (B,2,T), iters (B,), history lists)."""
+        compact: once fewer than `compact_below` of the trajectories in flight are still iterating (and
+        more than `compact_min` are in flight) the active ones are re-packed into a smaller batch, so
+        that converged trajectories stop costing passes; results do not depend on it.
+        Returns dict(xx_star (B,6,T), uu_star (B,2,T), iters (B,), converged, status, history of per-iteration
+        scalars (B,n_iter), NaN / -1 where a trajectory was no longer iterating)."""
         torch = _torch()
-        B, prm = self.B, self.params
+        B, prm, T = self.B, self.params, self.T
         dev = self.problem.device
-        active = torch.ones(self.Bp, dtype=torch.bool, device=dev)
-        iters = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
-        ret = torch.full((self.Bp,), -2, dtype=torch.int32, device=dev)  # returned history index (-2: not yet)
-        res_x = torch.zeros_like(self.xb[0])
-        res_u = torch.zeros_like(self.ub[0])
+        out_x = torch.zeros((B, 6, T), dtype=torch.float64, device=dev)
+        out_u = torch.zeros((B, 2, T), dtype=torch.float64, device=dev)
+        g_iters = torch.zeros(B, dtype=torch.int32, device=dev)
+        g_conv = torch.zeros(B, dtype=torch.bool, device=dev)
+        g_status = torch.zeros(B, dtype=torch.int32, device=dev)
         hist = dict(cost=[], descent=[], stepsize=[], ntrials=[])
+
+        def fresh(sv):
+            act = torch.zeros(sv.Bp, dtype=torch.bool, device=dev)
+            act[:sv.B] = True
+            return dict(active=act, ret=torch.full((sv.Bp,), -2, dtype=torch.int32, device=dev),
+                        res_x=torch.zeros_like(sv.xb[0]), res_u=torch.zeros_like(sv.ub[0]))
+
+        def flush(sv, gidx, L, final_kk=None):
+            """write the results of this generation's finished trajectories into the global arrays"""
+            n = sv.B
+            if final_kk is not None:  # still iterating at the end: the last computed iterate (index max_iters-1)
+                m = L["active"].reshape(sv.nt, 1, 1, TILE)
+                L["res_x"] = torch.where(m, sv.xb[sv.cur], L["res_x"])
+                L["res_u"] = torch.where(m, sv.ub[sv.cur], L["res_u"])
+                L["ret"] = torch.where(L["active"], torch.full_like(L["ret"], final_kk + 1), L["ret"])
+            ret = L["ret"][:n]
+            done = ret != -2
+            if bool(done.any()):
+                xs, us = unpack(L["res_x"], n), unpack(L["res_u"], n)
+                real = ret >= 0
+                xs[:, :, 0] = torch.where(real[:, None], unpack_vec(sv.x0, n), xs[:, :, 0])  # sample 0 is the fp64 x0
+                if sv.x_init is not None:  # index 0 is the caller's initial iterate, verbatim
+                    is0 = ret == 0
+                    xs = torch.where(is0[:, None, None], sv.x_init, xs)
+                    us = torch.where(is0[:, None, None], sv.u_init, us)
+                us[:, :, -1] = us[:, :, -2]  # optcon.py:505
+                tgt = gidx[done]
+                out_x[tgt], out_u[tgt] = xs[done], us[done]
+            g_status[gidx] |= sv.status[:n]
+
+        sv, gidx = self, torch.arange(B, device=dev)
+        L = fresh(sv)
         last = -1
         for kk in range(prm.max_iters - 1):
-            self.iterate(kk)
+            sv.iterate(kk)
             last = kk
-            for k_, v in self.scalars().items():
-                if k_ in hist:
-                    hist[k_].append(v)
-            conv = active & (self.descent >= prm.term_cond)
-            iters = torch.where(active, torch.full_like(iters, kk + 1), iters)
+            n = sv.B
+            sc = sv.scalars()
+            gnp = gidx.cpu().numpy()
+            for k_ in hist:
+                full = np.full(B, -1, dtype=np.int64) if k_ == "ntrials" else np.full(B, np.nan)
+                full[gnp] = sc[k_]
+                hist[k_].append(full)
+            act = L["active"]
+            conv = act & (sv.descent >= prm.term_cond)
+            g_iters[gidx[act[:n]]] = kk + 1
             if bool(conv.any()):
-                m = conv.reshape(self.nt, 1, 1, TILE)
+                m = conv.reshape(sv.nt, 1, 1, TILE)
                 if kk >= 1:  # iterate kk-1 lives two buffers behind the newest
-                    res_x = torch.where(m, self.xb[(self.cur + 1) % 3], res_x)
-                    res_u = torch.where(m, self.ub[(self.cur + 1) % 3], res_u)
+                    L["res_x"] = torch.where(m, sv.xb[(sv.cur + 1) % 3], L["res_x"])
+                    L["res_u"] = torch.where(m, sv.ub[(sv.cur + 1) % 3], L["res_u"])
                 # kk == 0: xx[:,:,-1] is the untouched, all-zero last history slot
-                ret = torch.where(conv, torch.full_like(ret, kk - 1), ret)
-                self.status |= conv.to(torch.int32) * _lib.ST_CONVERGED
-                active = active & ~conv
+                L["ret"] = torch.where(conv, torch.full_like(L["ret"], kk - 1), L["ret"])
+                sv.status |= conv.to(torch.int32) * _lib.ST_CONVERGED
+                g_conv[gidx[conv[:n]]] = True
+                L["active"] = act = act & ~conv
             if callback is not None:
-                callback(kk, self.scalars())
+                callback(kk, sc)
+            n_act = int(act.sum())
             if verbose:
-                s = self.scalars()
-                print("Iter = %d\t Descent = %r\t Cost = %r\t active = %d" %
-                      (kk, float(s["descent"][0]), float(s["cost"][0]), int(active[:B].sum())))
-            if not bool(active[:B].any()):
+                print("Iter = %d\t in flight = %d\t still iterating = %d" % (kk, n, n_act))
+            if n_act == 0:
                 break
-        # trajectories that never converged return the last computed iterate (index max_iters-1)
-        m = active.reshape(self.nt, 1, 1, TILE)
-        res_x = torch.where(m, self.xb[self.cur], res_x)
-        res_u = torch.where(m, self.ub[self.cur], res_u)
-        ret = torch.where(active, torch.full_like(ret, last + 1), ret)
-        xs = unpack(res_x, B)
-        us = unpack(res_u, B)
-        retB = ret[:B]
-        real = retB >= 0
-        xs[:, :, 0] = torch.where(real[:, None], unpack_vec(self.x0, B), xs[:, :, 0])  # sample 0 is the fp64 x0
-        if self.x_init is not None:  # index 0 is the caller's initial iterate, verbatim
-            is0 = retB == 0
-            xs = torch.where(is0[:, None, None], self.x_init, xs)
-            us = torch.where(is0[:, None, None], self.u_init, us)
-        us[:, :, -1] = us[:, :, -2]  # optcon.py:505
-        return dict(xx_star=xs.cpu().numpy(), uu_star=us.cpu().numpy(), iters=iters[:B].cpu().numpy(),
-                    converged=(~active[:B]).cpu().numpy(), status=self.status[:B].cpu().numpy(),
+            if compact and n > compact_min and n_act < compact_below * n and kk < prm.max_iters - 2:
+                keep = torch.nonzero(act[:n]).squeeze(1)
+                flush(sv, gidx, L)
+                sv, gidx = sv._compacted(keep), gidx[keep]
+                L = fresh(sv)
+        flush(sv, gidx, L, final_kk=last)
+        return dict(xx_star=out_x.cpu().numpy(), uu_star=out_u.cpu().numpy(), iters=g_iters.cpu().numpy(),
+                    converged=g_conv.cpu().numpy(), status=g_status.cpu().numpy(),
                     history={k_: np.stack(v, 1) if v else np.zeros((B, 0)) for k_, v in hist.items()},
                     last_kk=last)
 
 
-# ------------------------------------------------------------------------------------------------
-# pass level (thin functional wrappers used by the drop-in modules and the parity tests)
-# ------------------------------------------------------------------------------------------------
 def traj_cost(problem, xx, uu):
     """Cost of stored trajectories (reference optcon.py:417-424).  xx (B,6,T), uu (B,2,T) -> (B,)"""
     torch = _torch()
