@@ -407,7 +407,9 @@ class NewtonBatchSolver:
                 us[:, :, -1] = us[:, :, -2]  # optcon.py:505
                 tgt = gidx[done]
                 out_x[tgt], out_u[tgt] = xs[done], us[done]
-            g_status[gidx] |= sv.status[:n]
+            if final_kk is not None:  # status of the trajectories that never stopped
+                live = L["active"][:n]
+                g_status[gidx[live]] = sv.status[:n][live]
 
         sv, gidx = self, torch.arange(B, device=dev)
         L = fresh(sv)
@@ -434,6 +436,7 @@ class NewtonBatchSolver:
                 L["ret"] = torch.where(conv, torch.full_like(L["ret"], kk - 1), L["ret"])
                 sv.status |= conv.to(torch.int32) * _lib.ST_CONVERGED
                 g_conv[gidx[conv[:n]]] = True
+                g_status[gidx[conv[:n]]] = sv.status[:n][conv[:n]]  # events up to the stopping iteration
                 L["active"] = act = act & ~conv
             if callback is not None:
                 callback(kk, sc)
