@@ -419,12 +419,13 @@ class NewtonBatchSolver:
             last = kk
             n = sv.B
             sc = sv.scalars()
-            gnp = gidx.cpu().numpy()
+            act = L["active"]
+            was = act[:n].cpu().numpy()                 # iterating at the start of this iteration
+            gnp = gidx.cpu().numpy()[was]
             for k_ in hist:
                 full = np.full(B, -1, dtype=np.int64) if k_ == "ntrials" else np.full(B, np.nan)
-                full[gnp] = sc[k_]
+                full[gnp] = sc[k_][was]
                 hist[k_].append(full)
-            act = L["active"]
             conv = act & (sv.descent >= prm.term_cond)
             g_iters[gidx[act[:n]]] = kk + 1
             if bool(conv.any()):
