@@ -91,7 +91,9 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // forward declarations used by the launch functions
 extern "C" int32_t aoc_ntiles(int32_t B);
 extern "C" size_t aoc_tiled_elems(int32_t B, int32_t T, int32_t C);
-extern "C" size_t aoc_linesearch_scratch_bytes(int32_t B);
+extern "C" size_t aoc_linesearch_scratch_bytes(int32_t B, int32_t T);
+// tiles of the dense copy the line search may make of its searching trajectories (aoc_passes.inc, k_ls_gather)
+static inline int ls_dense_tiles(int32_t B) { const int nt = (B + 63) / 64; return nt < 256 ? nt : 256; }
 
 #define AOC_ARITH_NS aoc64
 #define AOC_REAL double
@@ -158,10 +160,13 @@ int aoc_unpack_f32(int32_t B, int32_t T, int32_t C, const float* src, double* ds
 }
 
 
-size_t aoc_linesearch_scratch_bytes(int32_t B) {
-    const size_t nt = (size_t)aoc_ntiles(B);
+size_t aoc_linesearch_scratch_bytes(int32_t B, int32_t T) {
+    const size_t nt = (size_t)aoc_ntiles(B), dt = (size_t)ls_dense_tiles(B);
+    // the fp64 layout bounds the float32 one
     return align_up(nt * sizeof(unsigned long long), 16) + align_up((nt + 1) * sizeof(int), 16) +
-           align_up(nt * TILE * sizeof(int), 16) + align_up(sizeof(aoc64::LsState), 16);  // the fp64 layout bounds the float32 one
+           align_up(nt * TILE * sizeof(int), 16) + align_up(sizeof(aoc64::LsState), 16) +
+           2 * align_up(dt * (size_t)T * 2 * TILE * sizeof(double), 16) + align_up(dt * 6 * TILE * sizeof(double), 16) +
+           2 * align_up(dt * TILE * sizeof(double), 16) + align_up(dt * TILE * sizeof(int), 16);
 }
 
 

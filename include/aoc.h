@@ -180,11 +180,12 @@ int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, 
  * cc*alpha_ii*descent; trials 0..n_spec-1 are judged from J_trial (written by aoc_forward).
  * Trajectories still rejected are compacted and searched in rounds; when few remain a round
  * evaluates several candidate steps of each at once (the accepted index is the first one that
- * passes, as in the reference's sequential loop).  On exhaustion the untested
+ * passes, as in the reference's sequential loop); when very few remain they are copied into a
+ * dense batch inside `scratch` and all their remaining steps are tried there in one round.  On exhaustion the untested
  * stepsize_0*beta^armijo_maxiters is used (Q5).  Finally EVERY trajectory is rolled out with its
  * step into x_new/u_new and J_new.  stepsize[b], ntrials[b] report the result.
- * armijo_maxiters <= 63.  scratch: device memory of aoc_linesearch_scratch_bytes(B) bytes. */
-size_t aoc_linesearch_scratch_bytes(int32_t B);
+ * armijo_maxiters <= 63.  scratch: device memory of aoc_linesearch_scratch_bytes(B, T) bytes. */
+size_t aoc_linesearch_scratch_bytes(int32_t B, int32_t T);
 int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const double *u,
                    const double *x0, const double *du, const double *J_cur, const double *descent,
                    const double *J_trial, void *x_new, double *u_new, double *J_new, double *stepsize,

@@ -313,12 +313,15 @@ def test_initial_trajectory_on_device(aoc):
         assert rel_err(xx[b], m["xx_init"][b], 1e-2) < 2e-4
 
 
-def test_linesearch_rounds_vs_oracle(aoc):
+@pytest.mark.parametrize("dense", ["0", "100000"])
+def test_linesearch_rounds_vs_oracle(aoc, dense, monkeypatch):
     """A1: the round-based back-tracking (compacted work list, several candidate steps of one
-    trajectory evaluated at once when few trajectories still search) accepts exactly the step and
-    reports exactly the trial count of the reference's sequential loop; checked against the oracle's
-    armijo_stepsize on the GPU's own iterates, over four iterations."""
+    trajectory evaluated at once when few trajectories still search; dense = "100000": the searching
+    trajectories copied into a dense batch and every remaining step tried there) accepts exactly the
+    step and reports exactly the trial count of the reference's sequential loop; checked against the
+    oracle's armijo_stepsize on the GPU's own iterates, over four iterations."""
     from aircraftoptimalcontrol_amd import problems
+    monkeypatch.setenv("AOC_LS_DENSE", dense)
     pr = problems.step_maneuver(1.0, 2e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     op = orc.OracleProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
