@@ -38,6 +38,7 @@ struct KConst {
     real hrho;   // 0.5*rho
     real krs;    // rho*S
     real b41;    // dt/J
+    real rJ;     // 1/J rounded to nearest (div_by_const)
     real Q[36], R[4], QT[36];
     int T, ntiles, B, diag;  // diag: Q,R,QT all diagonal (every driver of the reference)
 };
@@ -86,11 +87,14 @@ __device__ __forceinline__ void sincos_fast(double x, double* sp, double* cp) {
     const double cr = w + (((1.0 - w) - hz) + (z * z) * pc);
     // quadrant
     const bool swap = q & 1;
-    double s = swap ? cr : sr, c = swap ? sr : cr;
-    if (q & 2) s = -s;
-    if ((q + 1) & 2) c = -c;
-    *sp = s;
-    *cp = c;
+    const double s = swap ? cr : sr, c = swap ? sr : cr;
+    // sin changes sign in quadrants 2, 3 (bit 1 of q), cos in quadrants 1, 2 (bit 1 of q + 1): move that bit
+    // onto the sign bit with integer operations (two per value instead of and/compare/negate/select)
+    const unsigned qs = (unsigned)q << 30;
+    const unsigned long long fs = (unsigned long long)(qs & 0x80000000u) << 32;
+    const unsigned long long fc = (unsigned long long)((qs + 0x40000000u) & 0x80000000u) << 32;
+    *sp = __longlong_as_double(__double_as_longlong(s) ^ (long long)fs);
+    *cp = __longlong_as_double(__double_as_longlong(c) ^ (long long)fc);
 }
 __device__ __forceinline__ void sincos_fast(float x, float* sp, float* cp) { sincosf(x, sp, cp); }
 __device__ __forceinline__ void sincos_lib(double x, double* sp, double* cp) { sincos(x, sp, cp); }
@@ -112,6 +116,27 @@ __device__ __forceinline__ SC trig(real th, real ga) {
     return s;
 }
 
+// a / b for a wave-uniform b with rb = RN(1/b): q0 = RN(a rb), r = a - q0 b (exact, one fma), RN(q0 + r rb).
+// Markstein's correction: the result IS the correctly rounded quotient (b finite, not of all-ones
+// significand; a, a/b in the normal range), i.e. bit-identical to the reference's `uu[1] / J`, in three
+// instructions instead of the ~15 (one quarter-rate) of the IEEE division expansion.  a = +-inf gives NaN.
+__device__ __forceinline__ real div_by_const(real a, real b, real rb) {
+    const real q0 = a * rb;
+    const real r = __builtin_fma(-q0, b, a);
+    return __builtin_fma(r, rb, q0);
+}
+
+// 1/b to ~1 ulp for the linearisation and the 2x2 gain solve (results compared at 1e-8, not bit for bit):
+// v_rcp_f64 and two Newton steps, without the range scaling / fix-up of the IEEE expansion.
+__device__ __forceinline__ double rcp_fast(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ float rcp_fast(float b) { return 1.0f / b; }
+
 #pragma clang fp contract(off)
 __device__ __forceinline__ void step_state(const KConst& k, const real x[6], real u0, real u1,
                                            const SC& s, real xp[6]) {
@@ -123,7 +148,7 @@ __device__ __forceinline__ void step_state(const KConst& k, const real x[6], rea
     xp[1] = (real)(float)(x[1] - k.dt * V * s.sg);                    // :304
     xp[2] = (real)(float)(V + k.dtm * (-D - k.mg * s.sg + u0 * s.ca)); // :306
     xp[3] = (real)(float)(x[3] + k.dt * x[4]);                        // :307
-    xp[4] = (real)(float)(x[4] + k.dt * (u1 / k.J));                  // :309
+    xp[4] = (real)(float)(x[4] + k.dt * div_by_const(u1, k.J, k.rJ)); // :309  u1 / J
     xp[5] = (real)(float)(x[5] + (k.dt / (k.m * V)) * (L - k.mg * s.cg + u0 * s.sa)); // :310
 }
 
@@ -203,7 +228,7 @@ struct Lin {
 __device__ __forceinline__ Lin linearise(const KConst& k, const real x[6], real u0, const SC& s) {
     Lin l;
     const real V = x[2], al = x[3] - x[5], V2 = V * V;
-    const real iV = R(1.0) / V;
+    const real iV = rcp_fast(V);
     const real dtmV = k.dtm * iV;                     // dt/(m V)
     l.a02 = k.dt * s.cg;
     l.a05 = -k.dt * V * s.sg;
@@ -237,7 +262,7 @@ __device__ __forceinline__ Hess hessian(const KConst& k, const real x[6], real u
                                         const real lam[6]) {
     Hess h;
     const real V = x[2], al = x[3] - x[5], V2 = V * V;
-    const real iV = R(1.0) / V, iV2 = iV * iV;
+    const real iV = rcp_fast(V), iV2 = iV * iV;
     const real dtmV = k.dtm * iV, dtmV2 = k.dtm * iV2;
     const real l0 = lam[0], l1 = lam[1], l2 = lam[2], l5 = lam[5];
     // k = 0, 1  (:339-352)
@@ -330,7 +355,7 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, r
     StageFlags fl;
     const real det = M00 * M11 - M01 * M01;
     fl.singular = (det == R(0.0));
-    const real idet = R(1.0) / det;
+    const real idet = rcp_fast(det);
     const real i00 = M11 * idet, i01 = -M01 * idet, i11 = M00 * idet;
     // M positive definite <=> tr > 0 and det > 0 (equivalent to all(eigvals(M) > 0), optcon.py:745)
     const bool pd = (M00 + M11 > R(0.0)) && (det > R(0.0));
@@ -378,7 +403,7 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, r
         const real r00 = M00 + R(0.5), r11 = M11 + R(0.5);
         const real rdet = r00 * r11 - M01 * M01;
         if (rdet == R(0.0)) fl.singular = true;
-        const real ird = R(1.0) / rdet;
+        const real ird = rcp_fast(rdet);
         const real j00 = r11 * ird, j01 = -M01 * ird, j11 = r00 * ird;
         Kt[0] = -(j00 * h0 + j01 * h1); Kt[7] = -(j01 * h0 + j11 * h1);
 #pragma unroll
