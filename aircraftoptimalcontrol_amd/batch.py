@@ -6,6 +6,7 @@ reference's per-trajectory conventions stacked over the batch: xx (B,6,T), uu (B
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -456,6 +457,49 @@ class NewtonBatchSolver:
                     converged=g_conv.cpu().numpy(), status=g_status.cpu().numpy(),
                     history={k_: np.stack(v, 1) if v else np.zeros((B, 0)) for k_, v in hist.items()},
                     last_kk=last)
+
+    def solve_on_device(self, sync_every=4, history=True):
+        """solve() through aoc_newton_solve: the whole loop, stopping rule and return-index bookkeeping on
+        the device, the host only reads the count of still-iterating trajectories every `sync_every`
+        iterations (0: never; all max_iters-1 iterations run).  No re-packing: a stopped trajectory keeps
+        riding along in its tile.  Same return value as solve(); results are identical to solve(compact=False)."""
+        torch = _torch()
+        B, T, prm, dev = self.B, self.T, self.params, self.problem.device
+        n_it = max(int(prm.max_iters) - 1, 0)
+        x, f32 = self._xin()
+        p = self._p(f32, 1)
+        ws = torch.empty((lib().aoc_solve_workspace_bytes(B, T) + 7) // 8, dtype=torch.float64, device=dev)
+        x_star, u_star = torch.zeros_like(self.xb[0]), torch.zeros_like(self.ub[0])
+        iters = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
+        ret = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
+        status = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
+        hf = lambda dt: torch.empty((max(n_it, 1), self.Bp), dtype=dt, device=dev) if history else None
+        hc, hd, hs, hn = hf(torch.float64), hf(torch.float64), hf(torch.float64), hf(torch.int32)
+        n_run = C.c_int32(0)
+        torch.cuda.synchronize(dev)
+        t_start = time.perf_counter()
+        check(lib().aoc_newton_solve(C.byref(p), C.byref(prm), _ptr(x), _ptr(self.ub[self.cur]), _ptr(self.x0), _ptr(ws),
+                                     int(sync_every), _ptr(x_star), _ptr(u_star), _ptr(iters), _ptr(ret), _ptr(status),
+                                     _ptr(hc), _ptr(hd), _ptr(hs), _ptr(hn), C.byref(n_run)), "aoc_newton_solve")
+        torch.cuda.synchronize(dev)
+        t_device = time.perf_counter() - t_start   # the solve itself; the rest is unpacking and the copy to the host
+        del ws
+        r = ret[:B]
+        xs, us = unpack(x_star, B), unpack(u_star, B)
+        xs[:, :, 0] = torch.where((r >= 0)[:, None], unpack_vec(self.x0, B), xs[:, :, 0])  # sample 0 is the fp64 x0
+        if self.x_init is not None:  # index 0 is the caller's initial iterate, verbatim
+            is0 = r == 0
+            xs = torch.where(is0[:, None, None], self.x_init, xs)
+            us = torch.where(is0[:, None, None], self.u_init, us)
+            us[:, :, -1] = torch.where(is0[:, None], us[:, :, -2], us[:, :, -1])  # optcon.py:505
+        st = status[:B].cpu().numpy()
+        n = int(n_run.value)
+        hist = {}
+        for key, h in (("cost", hc), ("descent", hd), ("stepsize", hs), ("ntrials", hn)):
+            hist[key] = h[:n, :B].T.cpu().numpy() if history else np.zeros((B, 0))
+        return dict(xx_star=xs.cpu().numpy(), uu_star=us.cpu().numpy(), iters=iters[:B].cpu().numpy(),
+                    converged=(st & _lib.ST_CONVERGED) != 0, status=st, history=hist, last_kk=n - 1,
+                    device_seconds=t_device)
 
 
 def traj_cost(problem, xx, uu):

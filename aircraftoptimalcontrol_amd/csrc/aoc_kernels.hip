@@ -221,6 +221,15 @@ int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, 
                                      ntrials, status);
 }
 
+size_t aoc_solve_workspace_bytes(int32_t B, int32_t T) { return aoc64::api_solve_workspace_bytes(B, T); }
+int aoc_newton_solve(const aoc_problem* p, const aoc_params* prm, const void* x_init, const double* u_init,
+                     const double* x0, void* workspace, int32_t sync_every, void* x_star, double* u_star,
+                     int32_t* iters, int32_t* ret_index, int32_t* status, double* hist_cost, double* hist_descent,
+                     double* hist_stepsize, int32_t* hist_ntrials, int32_t* n_run) {
+    return aoc64::api_newton_solve(p, prm, x_init, u_init, x0, workspace, sync_every, x_star, u_star, iters, ret_index,
+                                   status, hist_cost, hist_descent, hist_stepsize, hist_ntrials, n_run);
+}
+
 // ---- float32 arithmetic (aoc32): every array, the reference curves and the workspace are float32 ------
 int aoc_traj_cost_f32(const aoc_problem* p, const float* x, const float* u, const float* x0, float* J) {
     return aoc32::api_traj_cost(p, x, u, x0, J);

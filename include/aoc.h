@@ -230,6 +230,39 @@ int aoc_newton_iterate(const aoc_problem *prob, const aoc_params *prm, int32_t k
                        int32_t *ntrials, int32_t *status);
 
 /* ---------------------------------------------------------------------------------------------
+ * Solve level: NewtonMethod.optimize (optcon.py:341-529) for every trajectory, termination included.
+ * --------------------------------------------------------------------------------------------- */
+size_t aoc_solve_workspace_bytes(int32_t B, int32_t T);
+
+/* The reference's outer loop kk = 0 .. max_iters-2 with its per-trajectory stopping rule, run on the
+ * device without returning to the host between iterations:
+ *   - cost of the initial iterate (optcon.py:417-424), then aoc_newton_iterate per kk for the WHOLE batch
+ *     (a stopped trajectory keeps riding along in its tile; its results are frozen);
+ *   - a trajectory stops at the first kk with descent[kk] >= prm->term_cond (optcon.py:499, Q6; a NaN
+ *     descent never stops) and returns iterate kk-1 (optcon.py:500-504, Q7): ret_index[b] = kk-1, where -1
+ *     means the reference's all-zero last history slot and 0 the initial iterate;
+ *   - a trajectory that never stops returns the last computed iterate, ret_index[b] = iterations run;
+ *   - u_star[:, T-1] = u_star[:, T-2] (optcon.py:505, Q8).
+ * (x_init, u_init): initial iterate, x_init of element type prob->x_in_f32, never written.  x0: fp64
+ * [ntiles][6][64], xx_init[:,0] of every trajectory (optcon.py:398).
+ * x_star (element type prob->x_out_f32), u_star: the returned iterates, tiled.  Sample 0 of x_star is the
+ *   stored copy of x0 (rounded if float32): take it from x0.  For ret_index = 0 x_star/u_star hold the
+ *   caller's initial iterate converted to the output type.
+ * iters[b]: iterations the trajectory took part in; status[b]: flags raised up to its stopping iteration,
+ *   AOC_ST_CONVERGED if it stopped by the descent test.
+ * hist_* (each may be NULL): per-iteration scalars [max_iters-1][ntiles*64] — cost of the iterate the iteration
+ *   started from, descent, accepted step, Armijo trials — NaN / -1 where the trajectory no longer iterated
+ *   (rows beyond *n_run are not written).
+ * sync_every: 0 = run all max_iters-1 iterations without any host synchronisation; n > 0 = every n
+ *   iterations read back the number of trajectories still iterating (one blocking 4-byte copy) and stop
+ *   launching when it is 0.  *n_run (host, may be NULL): iterations launched.
+ * workspace: aoc_solve_workspace_bytes(B,T) bytes of device memory. */
+int aoc_newton_solve(const aoc_problem *prob, const aoc_params *prm, const void *x_init, const double *u_init,
+                     const double *x0, void *workspace, int32_t sync_every, void *x_star, double *u_star,
+                     int32_t *iters, int32_t *ret_index, int32_t *status, double *hist_cost,
+                     double *hist_descent, double *hist_stepsize, int32_t *hist_ntrials, int32_t *n_run);
+
+/* ---------------------------------------------------------------------------------------------
  * float32 arithmetic (BASELINE.json configs[2]: "fp32 with tolerance sweep").
  * The same kernels compiled with float as the arithmetic type: EVERY array (states, inputs, gains,
  * costs, per-trajectory scalars, x0, the reference curves `prob->ref`, the workspace) is float32 and
