@@ -13,12 +13,13 @@ def find(prefix):
     ks = [k for k in p if k.startswith(prefix)]
     return max(ks, key=lambda k: p[k]["launches"]) if ks else None
 steps = 3  # pmc passes run 3 timed iterations with no warmup
-kb, kf, kfin, ktr = find("k_backward"), find("k_forward"), find("k_ls_final"), find("k_ls_trial")
-ls = p[kfin]["hbm_bytes_per_launch"] + p[ktr]["hbm_bytes_per_launch"] * p[ktr]["launches"] / steps
+kb, kf = find("k_backward"), find("k_forward")
+# every kernel of the line search (final pass, gathered and dense trial rounds, gather, bookkeeping), per iteration
+ls = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in p.items() if k.startswith("k_ls_")) / steps
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950), %s" % name,
        "batch_per_gpu": b["config"]["batch_per_gpu"], "T": b["config"]["T"],
        "kernels": {"backward": {"kernel": kb, "hbm_bytes_per_launch": p[kb]["hbm_bytes_per_launch"]},
                    "forward": {"kernel": kf, "hbm_bytes_per_launch": p[kf]["hbm_bytes_per_launch"]},
-                   "linesearch": {"kernel": "k_ls_final + k_ls_trial rounds of one iteration", "hbm_bytes_per_launch": ls}}}
+                   "linesearch": {"kernel": "all k_ls_* launches of one iteration (final pass, trial rounds, gather)", "hbm_bytes_per_launch": ls}}}
 json.dump(out, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
