@@ -96,7 +96,28 @@ __device__ __forceinline__ void sincos_fast(double x, double* sp, double* cp) {
     *sp = __longlong_as_double(__double_as_longlong(s) ^ (long long)fs);
     *cp = __longlong_as_double(__double_as_longlong(c) ^ (long long)fc);
 }
-__device__ __forceinline__ void sincos_fast(float x, float* sp, float* cp) { sincosf(x, sp, cp); }
+// float32 arithmetic (config 3): the same scheme in single precision — three-step Cody-Waite by pi/2, the
+// classic degree-7 / degree-8 kernels on [-pi/4, pi/4] (~1 ulp), branch-free; the library's sincosf (with its
+// large-argument path) only for finite |x| >= 2^17, see trig().
+__device__ __forceinline__ void sincos_fast(float x, float* sp, float* cp) {
+    const float n = __builtin_rintf(x * 6.36619772367581382433e-01f);
+    float r = __builtin_fmaf(-n, 1.57079625129699707031e+00f, x);
+    r = __builtin_fmaf(-n, 7.54978941586159635335e-08f, r);
+    r = __builtin_fmaf(-n, 5.39030285815811905290e-15f, r);
+    const int q = (int)n;
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+    const float sr = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+    const float cr = __builtin_fmaf(z * z, pc, __builtin_fmaf(z, -0.5f, 1.0f));
+    const bool swap = q & 1;
+    const float s = swap ? cr : sr, c = swap ? sr : cr;
+    const unsigned qs = (unsigned)q << 30;
+    *sp = __uint_as_float(__float_as_uint(s) ^ (qs & 0x80000000u));
+    *cp = __uint_as_float(__float_as_uint(c) ^ ((qs + 0x40000000u) & 0x80000000u));
+}
 __device__ __forceinline__ void sincos_lib(double x, double* sp, double* cp) { sincos(x, sp, cp); }
 __device__ __forceinline__ void sincos_lib(float x, float* sp, float* cp) { sincosf(x, sp, cp); }
 
@@ -113,7 +134,8 @@ __device__ __forceinline__ SC trig(real th, real ga) {
     // trajectory is NaN from some stage on; sending it through the library made its wavefront the straggler
     // of the launch: 13 NaN trajectories in 65 536 cost the forward pass +55 %.)
     const real aga = __builtin_fabs(ga), aal = __builtin_fabs(al), inf = __builtin_inf();
-    if ((aga >= R(1048576.0) && aga < inf) || (aal >= R(1048576.0) && aal < inf)) {
+    const real big = sizeof(real) == 8 ? R(1048576.0) : R(131072.0);  // where the Cody-Waite reduction stops being exact
+    if ((aga >= big && aga < inf) || (aal >= big && aal < inf)) {
         sincos_lib(ga, &s.sg, &s.cg);
         sincos_lib(al, &s.sa, &s.ca);
     }
