@@ -458,7 +458,7 @@ class NewtonBatchSolver:
                     history={k_: np.stack(v, 1) if v else np.zeros((B, 0)) for k_, v in hist.items()},
                     last_kk=last)
 
-    def solve_on_device(self, sync_every=4, history=True):
+    def solve_on_device(self, sync_every=4, history=True, x_star_f64=False):
         """solve() through aoc_newton_solve: the whole loop, stopping rule and return-index bookkeeping on
         the device, the host only reads the count of still-iterating trajectories every `sync_every`
         iterations (0: never; all max_iters-1 iterations run).  No re-packing: a stopped trajectory keeps
@@ -467,9 +467,10 @@ class NewtonBatchSolver:
         B, T, prm, dev = self.B, self.T, self.params, self.problem.device
         n_it = max(int(prm.max_iters) - 1, 0)
         x, f32 = self._xin()
-        p = self._p(f32, 1)
+        p = self._p(f32, 0 if x_star_f64 else 1)   # x_star as fp64 or float32 (the same values for iterates >= 1)
         ws = torch.empty((lib().aoc_solve_workspace_bytes(B, T) + 7) // 8, dtype=torch.float64, device=dev)
-        x_star, u_star = torch.zeros_like(self.xb[0]), torch.zeros_like(self.ub[0])
+        x_star = alloc_tiled(B, T, 6, dev, f32=not x_star_f64)
+        u_star = torch.zeros_like(self.ub[0])
         iters = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         ret = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         status = torch.zeros(self.Bp, dtype=torch.int32, device=dev)

@@ -518,6 +518,8 @@ def test_device_solve_return_index_edges(aoc):
         s.set_initial(xi, ui)
         dev = s.solve_on_device(sync_every=1)
         _same_solve(host, dev)
+        s.set_initial(xi, ui)
+        _same_solve(host, s.solve_on_device(sync_every=1, x_star_f64=True))   # x_star stored as fp64
     assert dev["iters"].tolist() == [3, 3] and not dev["converged"].any()
 
 
