@@ -76,6 +76,8 @@ SYMBOLS = {
     "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
     "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 8),
     "aoc_linesearch_scratch_bytes": (_Z, [_I, _I]),
+    "aoc_spec_max": (_I, []),
+    "aoc_default_nspec": (_I, [_I, _I]),
     "aoc_linesearch": (C.c_int, [_P, _P, _I] + [_P] * 13),
     "aoc_lqr_tracking": (C.c_int, [_P] * 9),
     "aoc_ltv_lqr": (C.c_int, [_I, _I, _I] + [_P] * 17),

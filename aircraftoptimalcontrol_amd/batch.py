@@ -203,7 +203,9 @@ class NewtonBatchSolver:
         self.ntrials = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         self.status = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         self.x0 = torch.zeros((self.nt, 6, TILE), dtype=torch.float64, device=dev)
-        self.n_spec = int(os.environ.get("AOC_NSPEC", "2"))  # Armijo trials riding along in the forward pass
+        # Armijo trials riding along in the forward pass: what aoc_newton_iterate uses for this batch size
+        self.n_spec = int(lib().aoc_default_nspec(self.B, int(self.params.armijo_maxiters)))
+        self.spec_max = int(lib().aoc_spec_max())
         self.cur = 0      # index of the buffer holding the current iterate
         self.kk = 0       # outer-iteration index of the current iterate
         self.jcur = 0
@@ -285,8 +287,8 @@ class NewtonBatchSolver:
         nel2 = lib().aoc_tiled_elems(self.B, self.T, 2)
         Kt, du = self.ws[:nel14], self.ws[nel14:nel14 + nel2]
         nsp = self.n_spec
-        Jt = self.ws[nel14 + nel2:nel14 + nel2 + 3 * self.Bp]
-        scratch = self.ws[nel14 + nel2 + 3 * self.Bp:]
+        Jt = self.ws[nel14 + nel2:nel14 + nel2 + self.spec_max * self.Bp]
+        scratch = self.ws[nel14 + nel2 + self.spec_max * self.Bp:]
         st = torch.cuda.current_stream(self.problem.device)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record(st)
@@ -346,7 +348,6 @@ class NewtonBatchSolver:
         n, dev = self.B, self.problem.device
         m = int(keep.numel())
         nw = NewtonBatchSolver(self.problem, m, self.params)
-        nw.n_spec = self.n_spec
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         for src, dst in (((self.cur - 1) % 3, 0), (self.cur, 1)):   # previous -> slot 0, current -> slot 1
             xs = unpack(self.xb[src], n)[keep].contiguous()

@@ -92,6 +92,8 @@ static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 extern "C" int32_t aoc_ntiles(int32_t B);
 extern "C" size_t aoc_tiled_elems(int32_t B, int32_t T, int32_t C);
 extern "C" size_t aoc_linesearch_scratch_bytes(int32_t B, int32_t T);
+extern "C" int32_t aoc_default_nspec(int32_t B, int32_t armijo_maxiters);
+constexpr int AOC_SPEC_MAX = 15;   // Armijo candidates that may ride along in the forward pass (5 workgroups per tile)
 // tiles of the dense copy the line search may make of its searching trajectories (aoc_passes.inc, k_ls_gather)
 static inline int ls_dense_tiles(int32_t B) { const int nt = (B + 63) / 64; return nt < 256 ? nt : 256; }
 
@@ -159,6 +161,20 @@ int aoc_unpack_f32(int32_t B, int32_t T, int32_t C, const float* src, double* ds
     return check_launch("k_unpack");
 }
 
+
+int32_t aoc_spec_max(void) { return AOC_SPEC_MAX; }
+
+// Number of Armijo candidates aoc_newton_iterate lets ride along in the forward pass.  2 in general (the pass is
+// bound by its K~ stream, two extra chains per lane are nearly free); for batches so small that one wavefront per
+// candidate still leaves SIMDs idle, all of them: the line search then needs no trial round.  AOC_NSPEC overrides.
+int32_t aoc_default_nspec(int32_t B, int32_t armijo_maxiters) {
+    const char* e = getenv("AOC_NSPEC");
+    if (e && atoi(e) > 0) return atoi(e) < AOC_SPEC_MAX ? atoi(e) : AOC_SPEC_MAX;
+    const long nt = aoc_ntiles(B);
+    // one workgroup (a CU: four SIMDs, four wavefronts) per three candidates and tile, 256 CUs
+    if (armijo_maxiters >= 1 && armijo_maxiters <= AOC_SPEC_MAX && nt * ((armijo_maxiters + 2) / 3) <= 256) return armijo_maxiters;
+    return armijo_maxiters < 2 ? 1 : 2;
+}
 
 size_t aoc_linesearch_scratch_bytes(int32_t B, int32_t T) {
     const size_t nt = (size_t)aoc_ntiles(B), dt = (size_t)ls_dense_tiles(B);

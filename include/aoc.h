@@ -166,7 +166,7 @@ int aoc_backward(const aoc_problem *prob, int32_t full_hessian, const void *x, c
  *   sum_t (B_t^T lambda_{t+1} + r_t)^T du_t   (optcon.py:474-477)
  * evaluated through the adjoint identity  sum_t (q_t^T dx_t + r_t^T du_t) + q_f^T dx_{T-1}  (same number,
  * 1e-13 relative on the golden cases; the costate then never leaves the backward pass); fused with
- * the first n_spec (1..3) Armijo trials: for step alpha_j = stepsize_0*beta^j, u' = u + alpha_j*du,
+ * the first n_spec (1..aoc_spec_max()) Armijo trials: for step alpha_j = stepsize_0*beta^j, u' = u + alpha_j*du,
  * nonlinear rollout x' from x0, cost J'_j (optcon.py:250-264).  The trials ride along with the K~
  * stream; the reference evaluates them one after the other, the verdict order is kept by
  * aoc_linesearch.
@@ -186,6 +186,11 @@ int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, 
  * step into x_new/u_new and J_new.  stepsize[b], ntrials[b] report the result.
  * armijo_maxiters <= 63.  scratch: device memory of aoc_linesearch_scratch_bytes(B, T) bytes. */
 size_t aoc_linesearch_scratch_bytes(int32_t B, int32_t T);
+/* Largest n_spec aoc_forward / aoc_linesearch take, and the n_spec aoc_newton_iterate uses for a batch of B
+ * trajectories: 2 in general, armijo_maxiters for batches small enough to give every candidate step its own
+ * wavefront (environment variable AOC_NSPEC overrides). */
+int32_t aoc_spec_max(void);
+int32_t aoc_default_nspec(int32_t B, int32_t armijo_maxiters);
 int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const double *u,
                    const double *x0, const double *du, const double *J_cur, const double *descent,
                    const double *J_trial, void *x_new, double *u_new, double *J_new, double *stepsize,
