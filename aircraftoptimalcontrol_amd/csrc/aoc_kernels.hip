@@ -171,8 +171,9 @@ int32_t aoc_default_nspec(int32_t B, int32_t armijo_maxiters) {
     const char* e = getenv("AOC_NSPEC");
     if (e && atoi(e) > 0) return atoi(e) < AOC_SPEC_MAX ? atoi(e) : AOC_SPEC_MAX;
     const long nt = aoc_ntiles(B);
-    // one workgroup (a CU: four SIMDs, four wavefronts) per three candidates and tile, 256 CUs
-    if (armijo_maxiters >= 1 && armijo_maxiters <= AOC_SPEC_MAX && nt * ((armijo_maxiters + 2) / 3) <= 256) return armijo_maxiters;
+    // one workgroup (four wavefronts, a CU's four SIMDs) per three candidates and tile; pays up to two workgroups
+    // per CU (measured: 8192 trajectories 1.89 -> 1.58 ms per iteration, 16 384 2.00 -> 2.21)
+    if (armijo_maxiters >= 1 && armijo_maxiters <= AOC_SPEC_MAX && nt * ((armijo_maxiters + 2) / 3) <= 512) return armijo_maxiters;
     return armijo_maxiters < 2 ? 1 : 2;
 }
 
