@@ -322,6 +322,7 @@ def test_linesearch_rounds_vs_oracle(aoc, dense, monkeypatch):
     oracle's armijo_stepsize on the GPU's own iterates, over four iterations."""
     from aircraftoptimalcontrol_amd import problems
     monkeypatch.setenv("AOC_LS_DENSE", dense)
+    monkeypatch.setenv("AOC_NSPEC", "2")   # a batch this small would otherwise try every step in the forward pass
     pr = problems.step_maneuver(1.0, 2e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     op = orc.OracleProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
@@ -541,3 +542,60 @@ def test_device_solve_with_repacking(aoc):
     spread = np.sort(host["iters"])
     assert spread[B // 2] < spread[-1], "iteration counts must spread for re-packing to happen"
     _same_solve(host, dev)
+
+
+def test_speculation_depth_does_not_change_results(aoc, monkeypatch):
+    """How many Armijo candidates ride along in the forward pass is a scheduling decision: 1, 2, 3 (one wavefront
+    per tile or one per chain) and all 10 (tiny batches: several workgroups per tile, no trial round at all) must
+    give bit-identical iterates, steps, trial counts and costs; aoc_default_nspec picks 10 for this batch."""
+    from aircraftoptimalcontrol_amd import problems, _lib
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 300
+    x0 = problems.random_x0(B, seed=31)
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    assert _lib.lib().aoc_default_nspec(B, 10) == 10 and _lib.lib().aoc_default_nspec(200000, 10) == 2
+    res = {}
+    for ns in ("1", "2", "3", "10", "7"):
+        monkeypatch.setenv("AOC_NSPEC", ns)
+        s = aoc.NewtonBatchSolver(bp, B, prm)
+        assert s.n_spec == int(ns)
+        s.set_initial_from_x0(x0)
+        hist = []
+        for kk in range(4):
+            s.iterate_timed(kk) if kk % 2 else s.iterate(kk)
+            hist.append(s.scalars())
+        res[ns] = (hist, s.current())
+    ha, (xa, ua) = res["2"]
+    assert max(h["ntrials"].max() for h in ha) > 3, "some trajectories must back-track beyond the speculated steps"
+    for ns in ("1", "3", "10", "7"):
+        hb, (xb, ub) = res[ns]
+        assert np.array_equal(xa, xb) and np.array_equal(ua, ub), ns
+        for a, b in zip(ha, hb):
+            for key in ("stepsize", "ntrials", "cost", "cost_new", "descent", "status"):
+                assert np.array_equal(a[key], b[key]), (ns, key)
+
+
+def test_split_kernels_equal_single_wavefront_kernels(aoc, monkeypatch):
+    """Small batches run the backward pass, the forward pass and the final rollout on several wavefronts per
+    tile (k_backward2, k_forward_split, k_ls_final_split); same operations on the same values, so the results
+    must equal those of the one-wavefront-per-tile kernels bit for bit, across the full-Hessian switch."""
+    from aircraftoptimalcontrol_amd import problems
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 200
+    x0 = problems.perturbed_x0(pr, B, seed=8)
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    monkeypatch.setenv("AOC_NSPEC", "2")
+    res = []
+    for tiles in ("0", "512"):
+        monkeypatch.setenv("AOC_SPLIT_TILES", tiles)
+        monkeypatch.setenv("AOC_SPLIT_BW_TILES", tiles)
+        s = aoc.NewtonBatchSolver(bp, B, prm)
+        s.set_initial_from_x0(x0)
+        res.append((s.run_fixed(11), s.current()))
+    (ha, (xa, ua)), (hb, (xb, ub)) = res
+    assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(ua, ub, equal_nan=True)
+    for a, b in zip(ha, hb):
+        for key in ("stepsize", "ntrials", "cost", "cost_new", "descent", "status"):
+            assert np.array_equal(a[key], b[key], equal_nan=True), key
