@@ -85,6 +85,7 @@ SYMBOLS = {
     "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 12),
     "aoc_solve_workspace_bytes": (_Z, [_I, _I]),
     "aoc_newton_solve": (C.c_int, [_P] * 6 + [_I] + [_P] * 10),
+    "aoc_mpc_step": (C.c_int, [_P] * 3 + [_I] + [_P] * 20),
     "aoc_traj_cost_f32": (C.c_int, [_P] * 5),
     "aoc_initial_trajectory_f32": (C.c_int, [_P, _D, _D, _P, _P, _P]),
     "aoc_rollout_cost_f32": (C.c_int, [_P] * 9),

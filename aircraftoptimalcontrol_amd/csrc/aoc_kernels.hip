@@ -247,6 +247,15 @@ int aoc_newton_solve(const aoc_problem* p, const aoc_params* prm, const void* x_
                                    status, hist_cost, hist_descent, hist_stepsize, hist_ntrials, n_run);
 }
 
+int aoc_mpc_step(const aoc_problem* p_track, const aoc_problem* p_next, const aoc_params* prm, int32_t n_newton,
+                 const void* x_cur, const double* u_cur, double* x0, double* x_true, const double* disturbance,
+                 void* workspace, double* Kgain, void* x_a, double* u_a, void* x_b, double* u_b, double* J_a, double* J_b,
+                 double* descent, double* stepsize, int32_t* ntrials, int32_t* status, double* K0, double* u_applied,
+                 int32_t* final_slot) {
+    return aoc64::api_mpc_step(p_track, p_next, prm, n_newton, x_cur, u_cur, x0, x_true, disturbance, workspace, Kgain, x_a,
+                               u_a, x_b, u_b, J_a, J_b, descent, stepsize, ntrials, status, K0, u_applied, final_slot);
+}
+
 // ---- float32 arithmetic (aoc32): every array, the reference curves and the workspace are float32 ------
 int aoc_traj_cost_f32(const aoc_problem* p, const float* x, const float* u, const float* x0, float* J) {
     return aoc32::api_traj_cost(p, x, u, x0, J);

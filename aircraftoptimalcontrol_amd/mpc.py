@@ -14,7 +14,8 @@ step being one of the reference's functions on the HIP library:
     5. re-solve  n_newton iterations of NewtonMethod.optimize with kk restarting at 0
                  (Gauss-Newton Hessian only, optcon.py:443)                           -> aoc_newton_iterate
 
-Host code here only moves pointers, shifts windows and draws the seeded disturbance.
+The whole step is one C-ABI call, aoc_mpc_step; host code here only advances the reference-window pointer and
+draws the seeded disturbance.
 """
 import ctypes as C
 
@@ -35,10 +36,11 @@ def window(ref_long, s, T):
 
 class RecedingHorizon:
     def __init__(self, pr, track_weights, B, T, n_newton=2, sigma=None, seed=20260405, device="cuda:0",
-                 stepsize_0=1.0, cc=0.5, beta=0.7, armijo_maxiters=10):
+                 stepsize_0=1.0, cc=0.5, beta=0.7, armijo_maxiters=10, horizon_steps=4096):
         """pr: problems.ProblemData (weights + long reference curves xx_ref (6,L), uu_ref (2,L), L >= T);
         track_weights: (QQt, RRt, QQT) of the tracking LQR; sigma: (6,) std of the additive state
-        disturbance per closed-loop step (None = none)."""
+        disturbance per closed-loop step (None = none); horizon_steps: how many steps the reference curve
+        kept on the device is extended for (its last sample is held)."""
         torch = _b._torch()
         self.pr, self.B, self.T, self.n_newton = pr, int(B), int(T), int(n_newton)
         self.device = torch.device(device)
@@ -48,19 +50,31 @@ class RecedingHorizon:
         self.prm = _b.make_params(max_iters=n_newton + 1, stepsize_0=stepsize_0, cc=cc, beta=beta,
                                   armijo_maxiters=armijo_maxiters)
         self.s = 0
-        self._set_window(0)
-        self.solver = _b.NewtonBatchSolver(self.prob, self.B, self.prm)
-        self.x_true = None
-        self.Kg = _b.alloc_tiled(self.B, self.T, 12, self.device)
-
-    def _set_window(self, s):
-        pr, T = self.pr, self.T
-        xr, ur = window(pr.xx_ref, s, T), window(pr.uu_ref, s, T)
+        # the whole (extended) reference curve lives on the device once; the window of step s is a pointer offset
+        n_long = max(pr.xx_ref.shape[1], self.T) + int(horizon_steps)
+        self.ref_long = torch.from_numpy(np.concatenate([window(pr.xx_ref, 0, n_long), window(pr.uu_ref, 0, n_long)],
+                                                        axis=0).T.copy()).to(self.device)   # [n_long][8]
+        self.n_long = n_long
+        xr, ur = window(pr.xx_ref, 0, T), window(pr.uu_ref, 0, T)
         self.prob = _b.BatchProblem(pr.QQt, pr.RRt, pr.QQT, xr, ur, pr.dt, device=self.device)
         Q, R, QT = self.tw
         self.tprob = _b.BatchProblem(Q, R, QT, xr, ur, pr.dt, device=self.device)
-        if hasattr(self, "solver"):
-            self.solver.problem = self.prob
+        self.solver = _b.NewtonBatchSolver(self.prob, self.B, self.prm)
+        self._set_window(0)
+        self.x_true = None          # host copy (B,6) of the plant state
+        self.x_true_d = torch.zeros_like(self.solver.x0)
+        self.Kg = _b.alloc_tiled(self.B, self.T, 12, self.device)
+        self.K0_d = torch.zeros((self.solver.nt, 12, TILE), dtype=torch.float64, device=self.device)
+        self.ua_d = torch.zeros((self.solver.nt, 2, TILE), dtype=torch.float64, device=self.device)
+
+    def _set_window(self, s):
+        """Point both problems at the reference window [s, s+T) (a view into the device-resident curve)."""
+        if s + self.T > self.n_long:
+            raise ValueError("reference curve on the device exhausted: raise horizon_steps")
+        view = self.ref_long[s:s + self.T]
+        self.prob.ref = view
+        self.tprob.ref = view
+        self.prob.xx_ref, self.prob.uu_ref = window(self.pr.xx_ref, s, self.T), window(self.pr.uu_ref, s, self.T)
 
     def disturbance(self, s):
         """(B,6) additive state disturbance of closed-loop step s, keyed by (seed, s)."""
@@ -78,41 +92,34 @@ class RecedingHorizon:
             self.solver.iterate(kk)
         self.solver.params = self.prm
         self.x_true = np.array(x0, dtype=np.float64)
+        self.x_true_d.copy_(_b.pack_vec(self.x_true, self.device))
 
-    def step(self):
-        """One receding-horizon step.  Returns dict(u_applied (B,2), x_true (B,6), cost (B,), K0 (B,2,6))."""
-        torch = _b._torch()
-        sv, B, T, dev = self.solver, self.B, self.T, self.device
+    def step(self, fetch=True):
+        """One receding-horizon step on the device (aoc_mpc_step).  fetch: copy the per-instance results to
+        the host and return dict(u_applied (B,2), x_true (B,6), cost (B,), K0 (B,2,6)); with fetch=False nothing
+        is read back (the step is only enqueued) and None is returned."""
+        sv, B, dev = self.solver, self.B, self.device
         c = sv.cur
-        # 1. gains about the current optimum (weights of lqr_tracking.py:324-328)
-        p = self.tprob.c_problem(B, x_in_f32=1)
-        st = torch.zeros(sv.Bp, dtype=torch.int32, device=dev)
-        check(lib().aoc_lqr_tracking(C.byref(p), _b._ptr(sv.xb[c]), _b._ptr(sv.ub[c]), _b._ptr(sv.x0), None,
-                                     _b._ptr(self.Kg), None, None, _b._ptr(st)), "aoc_lqr_tracking")
-        K0 = _b.unpack_vec(self.Kg[:, 0], B).reshape(B, 2, 6)
-        x_opt0 = _b.unpack_vec(sv.x0, B)                    # sample 0 of the optimum is its x0
-        u_opt0 = _b.unpack_vec(sv.ub[c][:, 0], B)
-        # 2. one closed-loop plant step (lqr_tracking.py:280-281) + disturbance
-        xt = _b._dev_f64(self.x_true, dev)
-        u_cl = u_opt0 + torch.einsum("bij,bj->bi", K0, xt - x_opt0)
-        xp = _b.step_batch(self.prob.model, xt, u_cl, device=dev)[0]
-        x_next = xp + self.disturbance(self.s)
-        # 3. shift the input sequence and the reference window
-        ub = sv.ub[c]
-        ub[:, :T - 2] = ub[:, 1:T - 1].clone()              # u[T-2] repeats; u[T-1] stays 0
+        a, b = (c + 1) % 3, (c + 2) % 3
+        dist = self.disturbance(self.s)
+        dist_d = _b.pack_vec(dist, dev) if self.sigma is not None else None
+        p_track = self.tprob.c_problem(B, x_in_f32=1, x_out_f32=1)
         self.s += 1
         self._set_window(self.s)
-        # 4. warm start: x0 <- plant state, initial iterate = rollout of the shifted inputs
-        sv.x0.copy_(_b.pack_vec(x_next, dev))
-        n = (c + 1) % 3
-        p = self.prob.c_problem(B, x_out_f32=1)
-        J0 = sv.J[sv.jcur]
-        check(lib().aoc_rollout_cost(C.byref(p), _b._ptr(sv.x0), _b._ptr(ub), None, None, _b._ptr(sv.xb[n]),
-                                     _b._ptr(sv.ub[n]), _b._ptr(J0), _b._ptr(sv.status)), "aoc_rollout_cost")
-        sv.cur, sv.cur_is64 = n, False
-        # 5. re-solve: kk restarts at 0
-        for kk in range(self.n_newton):
-            sv.iterate(kk)
-        self.x_true = x_next
-        return dict(u_applied=u_cl.cpu().numpy(), x_true=x_next.copy(), cost=sv.J[sv.jcur][:B].cpu().numpy(),
-                    K0=K0.cpu().numpy())
+        p_next = self.prob.c_problem(B, x_in_f32=1, x_out_f32=1)
+        slot = C.c_int32(0)
+        check(lib().aoc_mpc_step(C.byref(p_track), C.byref(p_next), C.byref(self.prm), self.n_newton,
+                                 _b._ptr(sv.xb[c]), _b._ptr(sv.ub[c]), _b._ptr(sv.x0), _b._ptr(self.x_true_d),
+                                 _b._ptr(dist_d), _b._ptr(sv.ws), _b._ptr(self.Kg), _b._ptr(sv.xb[a]), _b._ptr(sv.ub[a]),
+                                 _b._ptr(sv.xb[b]), _b._ptr(sv.ub[b]), _b._ptr(sv.J[0]), _b._ptr(sv.J[1]),
+                                 _b._ptr(sv.descent), _b._ptr(sv.stepsize), _b._ptr(sv.ntrials), _b._ptr(sv.status),
+                                 _b._ptr(self.K0_d), _b._ptr(self.ua_d), C.byref(slot)), "aoc_mpc_step")
+        sv.cur = a if slot.value == 0 else b
+        sv.jcur, sv.cur_is64, sv.kk = int(slot.value), False, self.n_newton
+        if not fetch:
+            self.x_true = None
+            return None
+        self.x_true = _b.unpack_vec(self.x_true_d, B).cpu().numpy()
+        return dict(u_applied=_b.unpack_vec(self.ua_d, B).cpu().numpy(), x_true=self.x_true.copy(),
+                    cost=sv.J[sv.jcur][:B].cpu().numpy(),
+                    K0=_b.unpack_vec(self.K0_d, B).reshape(B, 2, 6).cpu().numpy())

@@ -268,6 +268,27 @@ int aoc_newton_solve(const aoc_problem *prob, const aoc_params *prm, const void 
                      double *hist_descent, double *hist_stepsize, int32_t *hist_ntrials, int32_t *n_run);
 
 /* ---------------------------------------------------------------------------------------------
+ * Receding horizon (BASELINE.json configs[4]; the reference has no MPC, the loop is SURVEY 8d's "Config 5"
+ * built from the reference's pieces).  One step for every instance, entirely on the device:
+ *   1. gains K about the current optimum (x_cur,u_cur; sample 0 of x_cur is x0), weights of prob_track
+ *      (lqr_tracking.py:268-276, :324-328) -> Kgain (tiled C=12, as aoc_lqr_tracking); K0 = K[:,:,0]
+ *   2. plant: u_applied = u_cur[:,0] + K0 (x_true - x0)  (lqr_tracking.py:280),
+ *             x_true <- Dynamics.step(x_true, u_applied)[0] + disturbance  (lqr_tracking.py:281), x0 <- x_true
+ *   3. inputs shifted by one sample (the last one repeats), 4. warm start = their rollout from the new x0
+ *      (get_update with step 0, optcon.py:176-200) against prob_next, whose `ref` is the reference window of the
+ *      NEXT step
+ *   5. n_newton iterations of aoc_newton_iterate with kk restarting at 0 (Gauss-Newton Hessian only).
+ * State arrays are float32 (prob->x_in_f32 = x_out_f32 = 1).  (x_a,u_a,J_a) and (x_b,u_b,J_b): two iterate
+ * buffers distinct from (x_cur,u_cur); *final_slot (host) = 0 / 1: which of them holds the new optimum and
+ * its cost.  x0, x_true, disturbance (may be NULL), K0 ([ntiles][12][64], may be NULL), u_applied
+ * ([ntiles][2][64]): per-instance vectors laid out like x0.  workspace: aoc_workspace_bytes(B,T). */
+int aoc_mpc_step(const aoc_problem *prob_track, const aoc_problem *prob_next, const aoc_params *prm,
+                 int32_t n_newton, const void *x_cur, const double *u_cur, double *x0, double *x_true,
+                 const double *disturbance, void *workspace, double *Kgain, void *x_a, double *u_a, void *x_b,
+                 double *u_b, double *J_a, double *J_b, double *descent, double *stepsize, int32_t *ntrials,
+                 int32_t *status, double *K0, double *u_applied, int32_t *final_slot);
+
+/* ---------------------------------------------------------------------------------------------
  * float32 arithmetic (BASELINE.json configs[2]: "fp32 with tolerance sweep").
  * The same kernels compiled with float as the arithmetic type: EVERY array (states, inputs, gains,
  * costs, per-trajectory scalars, x0, the reference curves `prob->ref`, the workspace) is float32 and
