@@ -24,6 +24,12 @@ constexpr int TILE = 64;
 }
 #endif
 
+// Contraction: products and sums are fused only where one source expression contains both ("on"), never across
+// statements at the back end's discretion ("fast", the HIP default).  The roundings of a function are then the
+// same in every kernel it is inlined into, which is what makes the multi-wavefront variants of a pass (aoc_passes.inc)
+// bit-identical to the one-wavefront ones.  State propagation, cost and Armijo test switch contraction off.
+#pragma clang fp contract(on)
+
 namespace AOC_ARITH_NS {
 using aoc_common::TILE;
 typedef AOC_REAL real;
@@ -240,7 +246,7 @@ __device__ __forceinline__ real term_cost2(const KConst& k, const real x[6],
     for (int j = 0; j < 6; j++) ll += v[j] * dx[j];
     return ll;
 }
-#pragma clang fp contract(fast)
+#pragma clang fp contract(on)
 
 // ---------------------------------------------------------------------------------------------
 // Linearisation  A = df/dx, B = df/du  at (x,u)   (aircraft_simplified.py:316-325)
