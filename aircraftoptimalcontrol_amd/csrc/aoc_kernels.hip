@@ -172,8 +172,14 @@ int32_t aoc_default_nspec(int32_t B, int32_t armijo_maxiters) {
     if (e && atoi(e) > 0) return atoi(e) < AOC_SPEC_MAX ? atoi(e) : AOC_SPEC_MAX;
     const long nt = aoc_ntiles(B);
     // one workgroup (four wavefronts, a CU's four SIMDs) per three candidates and tile; pays up to two workgroups
-    // per CU (measured: 8192 trajectories 1.89 -> 1.58 ms per iteration, 16 384 2.00 -> 2.21)
-    if (armijo_maxiters >= 1 && armijo_maxiters <= AOC_SPEC_MAX && nt * ((armijo_maxiters + 2) / 3) <= 512) return armijo_maxiters;
+    // per CU, i.e. tiles x groups <= 512.  Measured, ms per iteration with 2 candidates -> with this rule:
+    // 4096 trajectories 1.85 -> 1.44 (all 10), 8192 1.89 -> 1.58 (10), 10 240 1.81 -> 1.47 (9), 16 384 1.86 -> 1.78 (6);
+    // one group more than the rule allows: 12 288 with 9 candidates 1.92, 16 384 with 10 2.21.
+    if (armijo_maxiters >= 1 && armijo_maxiters <= AOC_SPEC_MAX) {
+        long g = (armijo_maxiters + 2) / 3;
+        if (512 / nt < g) g = 512 / nt;
+        if (g >= 2) return 3 * g < armijo_maxiters ? (int32_t)(3 * g) : armijo_maxiters;
+    }
     return armijo_maxiters < 2 ? 1 : 2;
 }
 
