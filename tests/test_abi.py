@@ -49,3 +49,23 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_SO", "/nonexistent/libaoc_hip.so")
     with pytest.raises(_lib.AocError):
         _lib.lib()
+
+
+def test_default_speculation_depth_is_host_logic():
+    """aoc_default_nspec: how many Armijo candidates ride along in the forward pass, by batch size (tiles x
+    workgroups of three candidates <= 512), capped by armijo_maxiters and aoc_spec_max(); no device involved."""
+    import os
+    lib = _lib.lib()
+    assert lib.aoc_spec_max() >= 10
+    old = os.environ.pop("AOC_NSPEC", None)
+    try:
+        for B, m, want in ((1, 10, 10), (4096, 10, 10), (8192, 10, 10), (8193, 10, 9), (10880, 10, 9), (10881, 10, 6),
+                           (16384, 10, 6), (16385, 10, 2), (131072, 10, 2), (64, 20, 2), (64, 1, 1), (64, 2, 2),
+                           (64, 4, 4), (64, 12, 12)):
+            assert lib.aoc_default_nspec(B, m) == want, (B, m, lib.aoc_default_nspec(B, m), want)
+        os.environ["AOC_NSPEC"] = "3"
+        assert lib.aoc_default_nspec(131072, 10) == 3
+    finally:
+        os.environ.pop("AOC_NSPEC", None)
+        if old is not None:
+            os.environ["AOC_NSPEC"] = old
