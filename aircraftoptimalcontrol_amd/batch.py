@@ -459,11 +459,13 @@ class NewtonBatchSolver:
                     history={k_: np.stack(v, 1) if v else np.zeros((B, 0)) for k_, v in hist.items()},
                     last_kk=last)
 
-    def solve_on_device(self, sync_every=4, history=True, x_star_f64=False):
+    def solve_on_device(self, sync_every=4, history=True, x_star_f64=False, to_host=True):
         """solve() through aoc_newton_solve: the whole loop, stopping rule and return-index bookkeeping on
         the device, the host only reads the count of still-iterating trajectories every `sync_every`
         iterations (0: never; all max_iters-1 iterations run).  No re-packing: a stopped trajectory keeps
-        riding along in its tile.  Same return value as solve(); results are identical to solve(compact=False)."""
+        riding along in its tile.  Same return value as solve(); results are identical to solve(compact=False).
+        to_host=False leaves xx_star (B,6,T) / uu_star (B,2,T) on the device as torch tensors (copying 65 536
+        trajectories to the host takes longer than solving them)."""
         torch = _torch()
         B, T, prm, dev = self.B, self.T, self.params, self.problem.device
         n_it = max(int(prm.max_iters) - 1, 0)
@@ -499,9 +501,9 @@ class NewtonBatchSolver:
         hist = {}
         for key, h in (("cost", hc), ("descent", hd), ("stepsize", hs), ("ntrials", hn)):
             hist[key] = h[:n, :B].T.cpu().numpy() if history else np.zeros((B, 0))
-        return dict(xx_star=xs.cpu().numpy(), uu_star=us.cpu().numpy(), iters=iters[:B].cpu().numpy(),
-                    converged=(st & _lib.ST_CONVERGED) != 0, status=st, history=hist, last_kk=n - 1,
-                    device_seconds=t_device)
+        return dict(xx_star=xs.cpu().numpy() if to_host else xs, uu_star=us.cpu().numpy() if to_host else us,
+                    iters=iters[:B].cpu().numpy(), converged=(st & _lib.ST_CONVERGED) != 0, status=st, history=hist,
+                    last_kk=n - 1, device_seconds=t_device)
 
 
 def traj_cost(problem, xx, uu):
