@@ -10,7 +10,8 @@
  *   - All array pointers are DEVICE pointers (HBM), allocated and owned by the caller; the
  *     library keeps no pointer after a call returns and allocates nothing.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls enqueue work
- *     on that stream and return; they do not synchronise.
+ *     on that stream and return; they do not synchronise (the one exception: aoc_newton_solve with
+ *     sync_every > 0 reads a 4-byte counter back every sync_every iterations).
  *   - Return value: AOC_OK (0) or a negative AOC_E* code; aoc_strerror() names it.  Numerical
  *     trouble of individual trajectories is reported in the per-trajectory `status` words, never by
  *     the return value.
