@@ -510,7 +510,7 @@ def test_device_solve_return_index_edges(aoc):
     xx0 = c["xx_init"].copy(); xx0[:, 1:] += 1e-9
     xi, ui = np.stack([xx0, c["xx_init"]]), np.stack([c["uu_init"], c["uu_init"]])
     d0, d1 = c["descent"][0], c["descent"][1]
-    for term, n_it in ((-1e30, 9), (0.5 * (d0 + d1), 9), (1e30, 4)):
+    for term, n_it in ((-1e30, 9), (0.5 * (d0 + d1), 9), (1e30, 1), (1e30, 2), (1e30, 4)):   # max_iters = 1: no iteration at all
         prm = aoc.make_params(max_iters=n_it, stepsize_0=1.0, armijo_maxiters=10, term_cond=term)
         s = aoc.NewtonBatchSolver(bp, 2, prm)
         s.set_initial(xi, ui)
