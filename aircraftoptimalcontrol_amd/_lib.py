@@ -53,12 +53,21 @@ class Problem(C.Structure):
 class Params(C.Structure):
     _fields_ = [("max_iters", C.c_int32), ("armijo_maxiters", C.c_int32), ("stepsize_0", C.c_double),
                 ("cc", C.c_double), ("beta", C.c_double), ("term_cond", C.c_double),
-                ("hessian_switch", C.c_int32), ("reserved", C.c_int32)]
+                ("hessian_switch", C.c_int32), ("overlap", C.c_int32)]
+
+
+class Tuning(C.Structure):
+    """aoc_tuning (include/aoc.h): scheduling knobs; results never depend on them."""
+    _fields_ = [(n, C.c_int32) for n in ("nspec", "split_tiles", "split_bw_tiles", "ls_dense", "ls_wcap", "ls_kgrow",
+                                         "trial_split", "solve_norepack", "ls_worklist", "ls_cpl", "ls_depth_min")] + \
+               [("reserved", C.c_int32 * 5)]
 
 
 # every symbol include/aoc.h declares: (name, restype, argtypes)
 _P, _I, _D, _Z = C.c_void_p, C.c_int32, C.c_double, C.c_size_t
 SYMBOLS = {
+    "aoc_get_tuning": (None, [_P]),
+    "aoc_set_tuning": (None, [_P]),
     "aoc_version": (C.c_char_p, []),
     "aoc_strerror": (C.c_char_p, [C.c_int]),
     "aoc_last_hip_error": (C.c_char_p, []),
@@ -79,9 +88,12 @@ SYMBOLS = {
     "aoc_spec_max": (_I, []),
     "aoc_default_nspec": (_I, [_I, _I]),
     "aoc_linesearch": (C.c_int, [_P, _P, _I] + [_P] * 13),
+    "aoc_linesearch_search": (C.c_int, [_P, _P, _I] + [_P] * 9),
+    "aoc_linesearch_update": (C.c_int, [_P] * 12),
     "aoc_lqr_tracking": (C.c_int, [_P] * 9),
     "aoc_ltv_lqr": (C.c_int, [_I, _I, _I] + [_P] * 17),
     "aoc_workspace_bytes": (_Z, [_I, _I]),
+    "aoc_overlap_split": (_I, [_I]),
     "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 12),
     "aoc_solve_workspace_bytes": (_Z, [_I, _I]),
     "aoc_newton_solve": (C.c_int, [_P] * 6 + [_I] + [_P] * 10),
@@ -121,6 +133,30 @@ def lib():
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+class tuning:
+    """Context manager over aoc_set_tuning(): `with tuning(nspec=2, ls_worklist=1): ...` overrides the named
+    knobs for the block and restores the previous settings afterwards (tests, tuning tools)."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        l = lib()
+        self.old = Tuning()
+        l.aoc_get_tuning(C.byref(self.old))
+        new = Tuning.from_buffer_copy(self.old)
+        for k, v in self.kw.items():
+            if k not in dict(Tuning._fields_) or k == "reserved":
+                raise AttributeError("aoc_tuning has no field %r" % k)
+            setattr(new, k, int(v))
+        l.aoc_set_tuning(C.byref(new))
+        return new
+
+    def __exit__(self, *exc):
+        lib().aoc_set_tuning(C.byref(self.old))
+        return False
 
 
 def check(rc, what=""):

@@ -22,11 +22,12 @@ def default_model(dt=1e-3):
 
 
 def make_params(max_iters=200, stepsize_0=1e-2, cc=0.5, beta=0.7, armijo_maxiters=20, term_cond=-1e-6,
-                hessian_switch=8):
+                hessian_switch=8, overlap=0):
     """NewtonMethod constructor defaults (reference optcon.py:335-339); term_cond is the value the
-    reference hard-codes (-1e-6, optcon.py:368), not the ignored constructor argument."""
+    reference hard-codes (-1e-6, optcon.py:368), not the ignored constructor argument.  overlap = 1: large
+    batches iterate as two staggered half batches on two streams (aoc_params.overlap; same results)."""
     return Params(int(max_iters), int(armijo_maxiters), float(stepsize_0), float(cc), float(beta),
-                  float(term_cond), int(hessian_switch), 0)
+                  float(term_cond), int(hessian_switch), int(overlap))
 
 
 def _torch():
@@ -257,6 +258,10 @@ class NewtonBatchSolver:
         check(lib().aoc_traj_cost(C.byref(p), _ptr(self.xb[0]), _ptr(self.ub[0]), _ptr(self.x0), _ptr(self.J[0])),
               "aoc_traj_cost")
 
+    def overlap_active(self):
+        """True if iterate() runs this batch as two staggered half batches (params.overlap and a batch large enough)."""
+        return bool(self.params.overlap) and lib().aoc_overlap_split(self.B) > 0
+
     def iterate(self, kk=None):
         """One outer iteration (steps A-G of SURVEY 3.2) for every trajectory; asynchronous."""
         if kk is None:
@@ -271,10 +276,13 @@ class NewtonBatchSolver:
                                        _ptr(self.ntrials), _ptr(self.status)), "aoc_newton_iterate")
         self.cur, self.jcur, self.kk, self.cur_is64 = n, jn, kk + 1, False
 
+    PASSES = ("backward", "forward", "linesearch_search", "linesearch_update")
+
     def iterate_timed(self, kk=None):
-        """Same launches as iterate(), issued pass by pass with HIP events recorded on the launch
-        stream between them.  Returns the four events (start, after backward, after forward, after
-        line search); read them after a synchronize with ev[i].elapsed_time(ev[i+1]) [ms]."""
+        """The launches of iterate() with overlap = 0, issued pass by pass with HIP events recorded on the launch
+        stream between them: backward | forward | line-search rounds (aoc_linesearch_search) | final rollout
+        (aoc_linesearch_update = k_ls_final).  Returns the five events; read them after a synchronize with
+        ev[i].elapsed_time(ev[i+1]) [ms], i indexing PASSES."""
         torch = _torch()
         if kk is None:
             kk = self.kk
@@ -290,7 +298,7 @@ class NewtonBatchSolver:
         Jt = self.ws[nel14 + nel2:nel14 + nel2 + self.spec_max * self.Bp]
         scratch = self.ws[nel14 + nel2 + self.spec_max * self.Bp:]
         st = torch.cuda.current_stream(self.problem.device)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record(st)
         check(lib().aoc_backward(C.byref(p), int(kk > prm.hessian_switch), _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
                                  _ptr(Kt), None, _ptr(self.status)), "aoc_backward")
@@ -299,11 +307,14 @@ class NewtonBatchSolver:
                                 _ptr(Kt), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status)),
               "aoc_forward")
         ev[2].record(st)
-        check(lib().aoc_linesearch(C.byref(p), C.byref(prm), nsp, _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
-                                   _ptr(self.J[jc]), _ptr(self.descent), _ptr(Jt), _ptr(self.xb[n]),
-                                   _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.stepsize), _ptr(self.ntrials),
-                                   _ptr(self.status), _ptr(scratch)), "aoc_linesearch")
+        check(lib().aoc_linesearch_search(C.byref(p), C.byref(prm), nsp, _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
+                                          _ptr(self.J[jc]), _ptr(self.descent), _ptr(Jt), _ptr(self.stepsize),
+                                          _ptr(self.ntrials), _ptr(scratch)), "aoc_linesearch_search")
         ev[3].record(st)
+        check(lib().aoc_linesearch_update(C.byref(p), C.byref(prm), _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
+                                          _ptr(self.xb[n]), _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.stepsize),
+                                          _ptr(self.ntrials), _ptr(self.status), _ptr(scratch)), "aoc_linesearch_update")
+        ev[4].record(st)
         self.cur, self.jcur, self.kk, self.cur_is64 = n, jn, kk + 1, False
         return ev
 

@@ -9,9 +9,11 @@
 // parity path) and float32 (aoc32, BASELINE config 3); this file holds what is common and the C-ABI.
 #include <hip/hip_runtime.h>
 
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "../../include/aoc.h"
 
@@ -71,6 +73,42 @@ static int check_launch(const char* what) {
     return AOC_OK;
 }
 
+// argument errors leave their reason where aoc_last_hip_error() finds it
+static int einval(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_hip_err, sizeof g_hip_err, fmt, ap);
+    va_end(ap);
+    return AOC_EINVAL;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scheduling knobs (aoc_tuning, include/aoc.h): environment read once, replaceable through aoc_set_tuning
+// ---------------------------------------------------------------------------------------------
+static aoc_tuning g_tuning;
+static std::once_flag g_tuning_once;
+
+static void tuning_defaults(aoc_tuning* t) {
+    auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
+    memset(t, 0, sizeof *t);
+    t->nspec = env("AOC_NSPEC", 0);
+    t->split_tiles = env("AOC_SPLIT_TILES", 512);
+    t->split_bw_tiles = env("AOC_SPLIT_BW_TILES", 512);
+    t->ls_dense = env("AOC_LS_DENSE", -1);
+    t->ls_wcap = env("AOC_LS_WCAP", 0);
+    t->ls_kgrow = env("AOC_LS_KGROW", 0);
+    t->trial_split = env("AOC_TRIAL_SPLIT", 1);
+    t->solve_norepack = env("AOC_SOLVE_NOREPACK", 0);
+    t->ls_worklist = env("AOC_LS_WORKLIST", -1);
+    t->ls_cpl = env("AOC_LS_CPL", 1);
+    t->ls_depth_min = env("AOC_LS_DEPTH_MIN", 2);
+}
+
+static const aoc_tuning& tuning() {
+    std::call_once(g_tuning_once, [] { tuning_defaults(&g_tuning); });
+    return g_tuning;
+}
+
 static bool is_diag(const double* M, int n) {
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++)
@@ -79,10 +117,14 @@ static bool is_diag(const double* M, int n) {
 }
 
 static int check_problem(const aoc_problem* p) {
-    if (!p || !p->ref) return AOC_EINVAL;
-    if (p->B < 1 || p->T < 3) return AOC_EINVAL;
-    // R must be symmetric for the 2x2 closed forms used by the gain solve
-    if (p->RRt[1] != p->RRt[2]) return AOC_EINVAL;
+    if (!p) return einval("aoc_problem is NULL");
+    if (!p->ref) return einval("aoc_problem.ref (reference curves) is NULL");
+    if (p->B < 1 || p->T < 3) return einval("aoc_problem: B = %d, T = %d (need B >= 1, T >= 3)", p->B, p->T);
+    // R must be symmetric for the 2x2 closed forms used by the gain solve (every driver of the reference uses a
+    // diagonal R; the reference itself would accept any R)
+    if (p->RRt[1] != p->RRt[2])
+        return einval("aoc_problem.RRt is not symmetric (R01 = %g, R10 = %g): the 2x2 gain solve needs R = R^T", p->RRt[1],
+                      p->RRt[2]);
     return AOC_OK;
 }
 
@@ -129,6 +171,16 @@ const char* aoc_strerror(int code) {
 
 const char* aoc_last_hip_error(void) { return g_hip_err; }
 
+void aoc_get_tuning(aoc_tuning* out) {
+    if (out) *out = tuning();
+}
+
+void aoc_set_tuning(const aoc_tuning* t) {
+    tuning();   // make sure the one-time initialisation cannot overwrite what is set here
+    if (t) g_tuning = *t;
+    else tuning_defaults(&g_tuning);
+}
+
 int32_t aoc_ntiles(int32_t B) { return (B + TILE - 1) / TILE; }
 
 size_t aoc_tiled_elems(int32_t B, int32_t T, int32_t C) { return (size_t)aoc_ntiles(B) * T * C * TILE; }
@@ -166,10 +218,10 @@ int32_t aoc_spec_max(void) { return AOC_SPEC_MAX; }
 
 // Number of Armijo candidates aoc_newton_iterate lets ride along in the forward pass.  2 in general (the pass is
 // bound by its K~ stream, two extra chains per lane are nearly free); for batches so small that one wavefront per
-// candidate still leaves SIMDs idle, all of them: the line search then needs no trial round.  AOC_NSPEC overrides.
+// candidate still leaves SIMDs idle, all of them: the line search then needs no trial round.  aoc_tuning.nspec overrides.
 int32_t aoc_default_nspec(int32_t B, int32_t armijo_maxiters) {
-    const char* e = getenv("AOC_NSPEC");
-    if (e && atoi(e) > 0) return atoi(e) < AOC_SPEC_MAX ? atoi(e) : AOC_SPEC_MAX;
+    const int forced = tuning().nspec;
+    if (forced > 0) return forced < AOC_SPEC_MAX ? forced : AOC_SPEC_MAX;
     const long nt = aoc_ntiles(B);
     // one workgroup (four wavefronts, a CU's four SIMDs) per three candidates and tile; pays up to two workgroups
     // per CU, i.e. tiles x groups <= 512.  Measured, ms per iteration with 2 candidates -> with this rule:
@@ -189,7 +241,9 @@ size_t aoc_linesearch_scratch_bytes(int32_t B, int32_t T) {
     return align_up(nt * sizeof(unsigned long long), 16) + align_up((nt + 1) * sizeof(int), 16) +
            align_up(nt * TILE * sizeof(int), 16) + align_up(sizeof(aoc64::LsState), 16) +
            2 * align_up(dt * (size_t)T * 2 * TILE * sizeof(double), 16) + align_up(dt * 6 * TILE * sizeof(double), 16) +
-           2 * align_up(dt * TILE * sizeof(double), 16) + align_up(dt * TILE * sizeof(int), 16);
+           2 * align_up(dt * TILE * sizeof(double), 16) + align_up(dt * TILE * sizeof(int), 16) +
+           align_up(nt * TILE * aoc64::LS_WL_IPL * sizeof(int2), 16) + align_up(nt * TILE * sizeof(int), 16) +
+           align_up(2 * aoc64::LS_WL_ROUNDS * sizeof(int), 16);
 }
 
 
@@ -226,6 +280,16 @@ int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, 
     return aoc64::api_linesearch(p, prm, n_spec, u, x0, du, J_cur, descent, J_trial, x_new, u_new, J_new, stepsize,
                                  ntrials, status, scratch);
 }
+int aoc_linesearch_search(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const double* u, const double* x0,
+                          const double* du, const double* J_cur, const double* descent, const double* J_trial,
+                          double* stepsize, int32_t* ntrials, void* scratch) {
+    return aoc64::api_ls_search(p, prm, n_spec, u, x0, du, J_cur, descent, J_trial, stepsize, ntrials, scratch);
+}
+int aoc_linesearch_update(const aoc_problem* p, const aoc_params* prm, const double* u, const double* x0, const double* du,
+                          void* x_new, double* u_new, double* J_new, double* stepsize, int32_t* ntrials, int32_t* status,
+                          void* scratch) {
+    return aoc64::api_ls_update(p, prm, u, x0, du, x_new, u_new, J_new, stepsize, ntrials, status, scratch);
+}
 int aoc_lqr_tracking(const aoc_problem* p, const void* x_opt, const double* u_opt, const double* x_opt0,
                      const double* x0_reg, double* Kgain, void* x_reg, double* u_reg, int32_t* status) {
     return aoc64::api_lqr_tracking(p, x_opt, u_opt, x_opt0, x0_reg, Kgain, x_reg, u_reg, status);
@@ -237,6 +301,7 @@ int aoc_ltv_lqr(int32_t nb, int32_t T, int32_t augmented, const double* A, const
     return aoc64::api_ltv_lqr(nb, T, augmented, A, Bm, Q, R, S, Qf, x0, q, r, qf, KK, PP, xx, uu, nreg, nsing, stream);
 }
 size_t aoc_workspace_bytes(int32_t B, int32_t T) { return aoc64::api_workspace_bytes(B, T); }
+int32_t aoc_overlap_split(int32_t B) { return B >= 1 ? aoc64::overlap_split_tiles(B) : 0; }
 int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, const void* x, const double* u,
                        const double* x0, const double* J_cur, void* workspace, void* x_new, double* u_new,
                        double* J_new, double* descent, double* stepsize, int32_t* ntrials, int32_t* status) {

@@ -99,8 +99,33 @@ typedef struct aoc_params {
     double beta;             /* optcon.py:229 */
     double term_cond;        /* -1e-6 hard-coded at optcon.py:368 (constructor value is ignored) */
     int32_t hessian_switch;  /* 8: full Hessian when kk > 8, optcon.py:443 */
-    int32_t reserved;
+    int32_t overlap;         /* scheduling, not in the reference: 1 = aoc_newton_iterate (and what is built on it) runs a
+                                large batch as two half batches, the second on a library-owned stream started when the
+                                first half's backward pass is done, so that one half streams through HBM while the other
+                                sits in its latency-bound line-search rounds; the caller's stream waits for both before
+                                the call's work counts as done.  Results are identical to overlap = 0. */
 } aoc_params;
+
+/* Scheduling knobs.  They select kernel variants and launch shapes only — results never depend on them
+ * (tests/test_gpu_parity.py checks bit-identity across settings).  The defaults are read ONCE per process, at
+ * the first call that needs them, from the environment variables named below; aoc_set_tuning() replaces them
+ * (test hook / tuning tools), aoc_set_tuning(NULL) restores the defaults. */
+typedef struct aoc_tuning {
+    int32_t nspec;          /* AOC_NSPEC        Armijo candidates riding along in the forward pass; 0 = by batch size */
+    int32_t split_tiles;    /* AOC_SPLIT_TILES  several wavefronts per tile in forward/final/rollout/gains up to this many tiles (512) */
+    int32_t split_bw_tiles; /* AOC_SPLIT_BW_TILES  ... in the backward pass (512) */
+    int32_t ls_dense;       /* AOC_LS_DENSE     round-based line search: dense-copy capacity in wavefronts; -1 = by batch size, 0 = off */
+    int32_t ls_wcap;        /* AOC_LS_WCAP      wavefronts a trial round may occupy (0 = 1024) / the first work list may take with every remaining candidate (0 = 2048) */
+    int32_t ls_kgrow;       /* AOC_LS_KGROW     round-based line search: growth of the candidates per round; 0 = by batch size */
+    int32_t trial_split;    /* AOC_TRIAL_SPLIT  two-wavefront trial kernels for latency-bound rounds (1) */
+    int32_t solve_norepack; /* AOC_SOLVE_NOREPACK  aoc_newton_solve never re-packs (0) */
+    int32_t ls_worklist;    /* AOC_LS_WORKLIST  work-list line search: -1 = above split_tiles tiles, 0 = never, 1 = always */
+    int32_t ls_cpl;         /* AOC_LS_CPL       work-list line search: candidate steps per work item / lane (1, 2 or 4; default 1) */
+    int32_t ls_depth_min;   /* AOC_LS_DEPTH_MIN work-list line search: candidates tried in the first round at least (2) */
+    int32_t reserved[5];
+} aoc_tuning;
+void aoc_get_tuning(aoc_tuning *out);
+void aoc_set_tuning(const aoc_tuning *t);
 
 const char *aoc_version(void);
 const char *aoc_strerror(int code);
@@ -179,10 +204,11 @@ int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, 
 /* Armijo back-tracking (optcon.py:243-273) and the final update (optcon.py:488-491).
  * Trial ii uses alpha_ii = stepsize_0*beta^ii and is accepted iff J'(alpha_ii) <= J_cur +
  * cc*alpha_ii*descent; trials 0..n_spec-1 are judged from J_trial (written by aoc_forward).
- * Trajectories still rejected are compacted and searched in rounds; when few remain a round
- * evaluates several candidate steps of each at once (the accepted index is the first one that
- * passes, as in the reference's sequential loop); when very few remain they are copied into a
- * dense batch inside `scratch` and all their remaining steps are tried there in one round.  On exhaustion the untested
+ * Trajectories still rejected search on: small batches in rounds over a compacted list, several
+ * candidate steps of each at once when few remain; large batches through a work list of (trajectory,
+ * up to four consecutive candidates) items, a lane carrying the rollouts of its candidates side by side
+ * from one read of (u, du).  The accepted index is the first one that passes, as in the reference's
+ * sequential loop, whatever the schedule (aoc_tuning).  On exhaustion the untested
  * stepsize_0*beta^armijo_maxiters is used (Q5).  Finally EVERY trajectory is rolled out with its
  * step into x_new/u_new and J_new.  stepsize[b], ntrials[b] report the result.
  * armijo_maxiters <= 63.  scratch: device memory of aoc_linesearch_scratch_bytes(B, T) bytes. */
@@ -196,6 +222,20 @@ int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, int32_t n_spe
                    const double *x0, const double *du, const double *J_cur, const double *descent,
                    const double *J_trial, void *x_new, double *u_new, double *J_new, double *stepsize,
                    int32_t *ntrials, int32_t *status, void *scratch);
+
+/* The two halves of aoc_linesearch, which is exactly _search followed by _update on the same arguments:
+ *   aoc_linesearch_search = armijo_stepsize for every trajectory (optcon.py:204-327): stepsize[b], ntrials[b]; the
+ *     verdicts of the last round stay in `scratch` until _update resolves them.  On entry ntrials[b] is read as a
+ *     scheduling hint — the trial count of the previous iteration, or anything — which decides how many candidate
+ *     steps a trajectory tries at once, never what it accepts;
+ *   aoc_linesearch_update = get_update with that step (optcon.py:488-491, :176-200): x_new, u_new, J_new, status.
+ * (Separate entry points so that a caller can time or overlap the latency-bound search and the streaming update.) */
+int aoc_linesearch_search(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const double *u,
+                          const double *x0, const double *du, const double *J_cur, const double *descent,
+                          const double *J_trial, double *stepsize, int32_t *ntrials, void *scratch);
+int aoc_linesearch_update(const aoc_problem *prob, const aoc_params *prm, const double *u, const double *x0,
+                          const double *du, void *x_new, double *u_new, double *J_new, double *stepsize,
+                          int32_t *ntrials, int32_t *status, void *scratch);
 
 /* lqr_tracking.lqr_tracking (lqr_tracking.py:245-283): linearise about (x_opt,u_opt), non-augmented
  * Riccati/gain recursion with the constant weights QQt,RRt,QQT of `prob` and S = 0
@@ -223,6 +263,9 @@ int aoc_ltv_lqr(int32_t nb, int32_t T, int32_t augmented, const double *A, const
  * Iteration level.  Workspace: caller-allocated device memory of aoc_workspace_bytes(B,T) bytes.
  * --------------------------------------------------------------------------------------------- */
 size_t aoc_workspace_bytes(int32_t B, int32_t T);
+/* Tiles of the first half when aoc_params.overlap = 1 cuts a batch of B trajectories in two; 0 = the batch is too
+ * small to be cut (its halves would no longer be large-batch launches) and overlap has no effect. */
+int32_t aoc_overlap_split(int32_t B);
 
 /* One outer iteration kk of NewtonMethod.optimize for every trajectory (optcon.py:415-491, steps
  * A-G of SURVEY 3.2): backward, forward, line search.  (x,u) current iterate, J_cur its cost

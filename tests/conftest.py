@@ -30,3 +30,25 @@ def rel_err(a, b, floor=1e-3):
     if a.size == 0:
         return 0.0
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+@pytest.fixture
+def tuned():
+    """tuned(**knobs): override scheduling knobs of the library (aoc_set_tuning) for the rest of the test; every
+    call starts again from the settings the test began with, which are restored at the end."""
+    import ctypes as C
+    from aircraftoptimalcontrol_amd import _lib
+    l = _lib.lib()
+    old = _lib.Tuning()
+    l.aoc_get_tuning(C.byref(old))
+
+    def set_(**kw):
+        new = _lib.Tuning.from_buffer_copy(old)
+        for k, v in kw.items():
+            assert k in dict(_lib.Tuning._fields_) and k != "reserved", k
+            setattr(new, k, int(v))
+        l.aoc_set_tuning(C.byref(new))
+        return new
+
+    yield set_
+    l.aoc_set_tuning(C.byref(old))

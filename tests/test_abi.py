@@ -38,6 +38,7 @@ def test_geometry_helpers_and_errors():
     assert C.sizeof(_lib.Model) == 72
     assert C.sizeof(_lib.Problem) == 72 + 76 * 8 + 16 + 16
     assert C.sizeof(_lib.Params) == 48
+    assert C.sizeof(_lib.Tuning) == 64
     # argument errors are reported before anything touches a device
     p = _lib.Problem()
     assert lib.aoc_traj_cost(C.byref(p), None, None, None, None) == -1
@@ -51,21 +52,54 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.lib()
 
 
-def test_default_speculation_depth_is_host_logic():
+def test_default_speculation_depth_is_host_logic(tuned):
     """aoc_default_nspec: how many Armijo candidates ride along in the forward pass, by batch size (tiles x
     workgroups of three candidates <= 512), capped by armijo_maxiters and aoc_spec_max(); no device involved."""
-    import os
     lib = _lib.lib()
     assert lib.aoc_spec_max() >= 10
-    old = os.environ.pop("AOC_NSPEC", None)
+    tuned(nspec=0)
+    for B, m, want in ((1, 10, 10), (4096, 10, 10), (8192, 10, 10), (8193, 10, 9), (10880, 10, 9), (10881, 10, 6),
+                       (16384, 10, 6), (16385, 10, 2), (131072, 10, 2), (64, 20, 2), (64, 1, 1), (64, 2, 2),
+                       (64, 4, 4), (64, 12, 12)):
+        assert lib.aoc_default_nspec(B, m) == want, (B, m, lib.aoc_default_nspec(B, m), want)
+    tuned(nspec=3)
+    assert lib.aoc_default_nspec(131072, 10) == 3
+
+
+def test_tuning_is_read_once_and_overridable():
+    """The scheduling knobs come from the environment ONCE (first use) and afterwards only through
+    aoc_set_tuning(); aoc_set_tuning(NULL) goes back to the defaults."""
+    import os
+    lib = _lib.lib()
+    t0 = _lib.Tuning()
+    lib.aoc_get_tuning(C.byref(t0))
+    os.environ["AOC_SPLIT_TILES"] = str(t0.split_tiles + 7)       # too late: already initialised
     try:
-        for B, m, want in ((1, 10, 10), (4096, 10, 10), (8192, 10, 10), (8193, 10, 9), (10880, 10, 9), (10881, 10, 6),
-                           (16384, 10, 6), (16385, 10, 2), (131072, 10, 2), (64, 20, 2), (64, 1, 1), (64, 2, 2),
-                           (64, 4, 4), (64, 12, 12)):
-            assert lib.aoc_default_nspec(B, m) == want, (B, m, lib.aoc_default_nspec(B, m), want)
-        os.environ["AOC_NSPEC"] = "3"
-        assert lib.aoc_default_nspec(131072, 10) == 3
+        t1 = _lib.Tuning()
+        lib.aoc_get_tuning(C.byref(t1))
+        assert t1.split_tiles == t0.split_tiles
+        with _lib.tuning(split_tiles=3, ls_cpl=2) as t:
+            assert (t.split_tiles, t.ls_cpl) == (3, 2)
+            lib.aoc_get_tuning(C.byref(t1))
+            assert (t1.split_tiles, t1.ls_cpl, t1.ls_wcap) == (3, 2, t0.ls_wcap)
+        lib.aoc_get_tuning(C.byref(t1))
+        assert bytes(t1) == bytes(t0)
+        lib.aoc_set_tuning(None)                                      # defaults = the environment as it is NOW
+        lib.aoc_get_tuning(C.byref(t1))
+        assert t1.split_tiles == t0.split_tiles + 7
     finally:
-        os.environ.pop("AOC_NSPEC", None)
-        if old is not None:
-            os.environ["AOC_NSPEC"] = old
+        os.environ.pop("AOC_SPLIT_TILES")
+        lib.aoc_set_tuning(C.byref(t0))
+
+
+def test_argument_errors_carry_a_reason():
+    lib = _lib.lib()
+    p = _lib.Problem()
+    p.B, p.T, p.ref = 4, 10, 1
+    p.RRt[1], p.RRt[2] = 1.0, 2.0
+    assert lib.aoc_traj_cost(C.byref(p), 1, 1, 1, 1) == -1
+    assert b"not symmetric" in lib.aoc_last_hip_error()
+    p.RRt[2] = 1.0
+    p.T = 2
+    assert lib.aoc_traj_cost(C.byref(p), 1, 1, 1, 1) == -1
+    assert b"T = 2" in lib.aoc_last_hip_error()

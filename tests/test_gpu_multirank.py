@@ -1,0 +1,72 @@
+"""SURVEY 8(e) on hardware that has one GPU: `bench.py --gpus 2` starts two ranks itself (both mapped to cuda:0,
+collective over gloo), each runs the REAL solver on its shard; every trajectory must equal the single-process run
+bit for bit, the all-reduced sums the single-process sums, and the line must say n_gpus: 2."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(tmp, gpus, per_gpu, steps=3):
+    d = tmp / ("n%d" % gpus)
+    d.mkdir()
+    env = dict(os.environ, AOC_BENCH_ONE_DEVICE="1", AOC_BENCH_BACKEND="gloo", AOC_BENCH_DUMP=str(d))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", str(steps),
+                        "--warmup", "1", "--batch-per-gpu", str(per_gpu), "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), [dict(np.load(d / ("rank%d_of_%d.npz" % (k, gpus)))) for k in range(gpus)]
+
+
+def test_two_ranks_through_the_real_solver_equal_one_process(tmp_path):
+    per = 4160                                  # 65 tiles per rank; the single process solves all 8320 at once
+    two, parts = _bench(tmp_path, 2, per)
+    one, (whole,) = _bench(tmp_path, 1, 2 * per)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["global_batch"] == 2 * per == one["config"]["global_batch"]
+    assert [int(p["first"]) for p in parts] == [0, per]
+    for key in ("xx", "uu", "cost", "cost_new", "descent", "stepsize", "ntrials", "status"):
+        both = np.concatenate([p[key] for p in parts])
+        assert np.array_equal(both, whole[key], equal_nan=True), key
+    # the path's one collective: both ranks hold the same reduced vector, equal to the single-process sums
+    assert np.array_equal(parts[0]["summary"], parts[1]["summary"])
+    assert np.allclose(parts[0]["summary"], whole["summary"], rtol=1e-12, atol=0)
+    assert parts[0]["summary"][3] == 2 * per
+    assert two["steps"] == 3 and two["value"] > 0 and two["scaling"] == "weak"
+    out = os.path.join(ROOT, "gpurun_out", "two_rank_rehearsal.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump({"two_ranks_one_device_gloo": two, "one_process": one}, open(out, "w"), indent=1)
+
+
+def test_overlap_mode_does_not_change_results():
+    """aoc_params.overlap = 1 (two staggered half batches on two streams) against one batch on one stream: iterates,
+    steps, trial counts and costs bit for bit, across the Hessian switch, on a batch large enough to be cut."""
+    import ctypes as C
+    from aircraftoptimalcontrol_amd import batch as aoc, problems, _lib
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 66000 + 37
+    assert _lib.lib().aoc_overlap_split(B) == (B + 63) // 64 // 2
+    x0 = problems.random_x0(B, seed=20260403)
+    res = []
+    for ov in (0, 1):
+        s = aoc.NewtonBatchSolver(bp, B, aoc.make_params(stepsize_0=1.0, armijo_maxiters=10, overlap=ov))
+        assert s.overlap_active() == bool(ov)
+        s.set_initial_from_x0(x0)
+        res.append((s.run_fixed(11), s.current()))
+        del s
+    (ha, (xa, ua)), (hb, (xb, ub)) = res
+    assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(ua, ub, equal_nan=True)
+    for a, b in zip(ha, hb):
+        for key in ("stepsize", "ntrials", "cost", "cost_new", "descent", "status"):
+            assert np.array_equal(a[key], b[key], equal_nan=True), key

@@ -313,16 +313,21 @@ def test_initial_trajectory_on_device(aoc):
         assert rel_err(xx[b], m["xx_init"][b], 1e-2) < 2e-4
 
 
-@pytest.mark.parametrize("dense", ["0", "100000"])
-def test_linesearch_rounds_vs_oracle(aoc, dense, monkeypatch):
-    """A1: the round-based back-tracking (compacted work list, several candidate steps of one
-    trajectory evaluated at once when few trajectories still search; dense = "100000": the searching
-    trajectories copied into a dense batch and every remaining step tried there) accepts exactly the
-    step and reports exactly the trial count of the reference's sequential loop; checked against the
-    oracle's armijo_stepsize on the GPU's own iterates, over four iterations."""
+LS_MODES = {"rounds": dict(ls_worklist=0, ls_dense=0), "rounds-dense": dict(ls_worklist=0, ls_dense=100000),
+            "worklist-cpl4": dict(ls_worklist=1, ls_cpl=4), "worklist-cpl2": dict(ls_worklist=1, ls_cpl=2),
+            "worklist-cpl1-depth1": dict(ls_worklist=1, ls_cpl=1, ls_depth_min=1)}
+
+
+@pytest.mark.parametrize("mode", sorted(LS_MODES))
+def test_linesearch_rounds_vs_oracle(aoc, mode, tuned):
+    """A1: every scheduling of the back-tracking — rounds over a compacted list with several candidate steps of
+    one trajectory evaluated at once when few trajectories still search; "dense": the searching trajectories copied
+    into a dense batch and every remaining step tried there; "worklist": (trajectory, up to cpl candidates) items,
+    depth predicted from the previous iteration's trial count — accepts exactly the step and reports exactly the
+    trial count of the reference's sequential loop; checked against the oracle's armijo_stepsize on the GPU's own
+    iterates, over four iterations."""
     from aircraftoptimalcontrol_amd import problems
-    monkeypatch.setenv("AOC_LS_DENSE", dense)
-    monkeypatch.setenv("AOC_NSPEC", "2")   # a batch this small would otherwise try every step in the forward pass
+    tuned(nspec=2, **LS_MODES[mode])   # a batch this small would otherwise try every step in the forward pass
     pr = problems.step_maneuver(1.0, 2e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     op = orc.OracleProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
@@ -544,7 +549,7 @@ def test_device_solve_with_repacking(aoc):
     _same_solve(host, dev)
 
 
-def test_speculation_depth_does_not_change_results(aoc, monkeypatch):
+def test_speculation_depth_does_not_change_results(aoc, tuned):
     """How many Armijo candidates ride along in the forward pass is a scheduling decision: 1, 2, 3 (one wavefront
     per tile or one per chain) and all 10 (tiny batches: several workgroups per tile, no trial round at all) must
     give bit-identical iterates, steps, trial counts and costs; aoc_default_nspec picks 10 for this batch."""
@@ -556,19 +561,19 @@ def test_speculation_depth_does_not_change_results(aoc, monkeypatch):
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
     assert _lib.lib().aoc_default_nspec(B, 10) == 10 and _lib.lib().aoc_default_nspec(200000, 10) == 2
     res = {}
-    for ns in ("1", "2", "3", "10", "7"):
-        monkeypatch.setenv("AOC_NSPEC", ns)
+    for ns, wl in ((1, 0), (2, 0), (3, 0), (10, 0), (7, 0), (2, 1), (3, 1)):
+        tuned(nspec=ns, ls_worklist=wl)
         s = aoc.NewtonBatchSolver(bp, B, prm)
-        assert s.n_spec == int(ns)
+        assert s.n_spec == ns
         s.set_initial_from_x0(x0)
         hist = []
         for kk in range(4):
             s.iterate_timed(kk) if kk % 2 else s.iterate(kk)
             hist.append(s.scalars())
-        res[ns] = (hist, s.current())
-    ha, (xa, ua) = res["2"]
+        res[ns, wl] = (hist, s.current())
+    ha, (xa, ua) = res[2, 0]
     assert max(h["ntrials"].max() for h in ha) > 3, "some trajectories must back-track beyond the speculated steps"
-    for ns in ("1", "3", "10", "7"):
+    for ns in sorted(res):
         hb, (xb, ub) = res[ns]
         assert np.array_equal(xa, xb) and np.array_equal(ua, ub), ns
         for a, b in zip(ha, hb):
@@ -576,7 +581,7 @@ def test_speculation_depth_does_not_change_results(aoc, monkeypatch):
                 assert np.array_equal(a[key], b[key]), (ns, key)
 
 
-def test_split_kernels_equal_single_wavefront_kernels(aoc, monkeypatch):
+def test_split_kernels_equal_single_wavefront_kernels(aoc, tuned):
     """Small batches run the backward pass, the forward pass and the final rollout on several wavefronts per
     tile (k_backward2, k_forward_split, k_ls_final_split); same operations on the same values, so the results
     must equal those of the one-wavefront-per-tile kernels bit for bit, across the full-Hessian switch."""
@@ -586,11 +591,9 @@ def test_split_kernels_equal_single_wavefront_kernels(aoc, monkeypatch):
     B = 200
     x0 = problems.perturbed_x0(pr, B, seed=8)
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
-    monkeypatch.setenv("AOC_NSPEC", "2")
     res = []
-    for tiles in ("0", "512"):
-        monkeypatch.setenv("AOC_SPLIT_TILES", tiles)
-        monkeypatch.setenv("AOC_SPLIT_BW_TILES", tiles)
+    for tiles in (0, 512):
+        tuned(nspec=2, split_tiles=tiles, split_bw_tiles=tiles, ls_worklist=0)
         s = aoc.NewtonBatchSolver(bp, B, prm)
         s.set_initial_from_x0(x0)
         res.append((s.run_fixed(11), s.current()))
@@ -600,8 +603,8 @@ def test_split_kernels_equal_single_wavefront_kernels(aoc, monkeypatch):
     tw = problems.tracking_weights()
     tp = aoc.BatchProblem(tw[0], tw[1], tw[2], pr.xx_ref, pr.uu_ref, pr.dt)
     outs = []
-    for tiles in ("0", "512"):
-        monkeypatch.setenv("AOC_SPLIT_TILES", tiles)
+    for tiles in (0, 512):
+        tuned(split_tiles=tiles)
         g = aoc.lqr_tracking_batch(tp, xa[:70], ua[:70], 0.1)
         r = aoc.rollout_cost(bp, x0[:70], ua[:70], du=0.3 * ua[:70], alpha=np.full(70, 0.7))
         outs.append((g, r))

@@ -58,10 +58,10 @@ def test_shard_range_partitions():
 WORKER = r'''
 import os, sys
 sys.path.insert(0, %r)
-import numpy as np, torch, torch.distributed as dist
+import numpy as np, torch
 from aircraftoptimalcontrol_amd import problems, sharding
-rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo")
+rank, local, world = sharding.env_rank_world()
+assert sharding.init_process_group("gloo") == world
 B = 1001
 first, n = sharding.shard_range(rank, world, B)
 x0 = problems.random_x0(n, seed=20260403, first=first)
@@ -71,14 +71,18 @@ if rank == 1: cost[3] = np.nan
 descent = -np.abs(x0[:, 4])
 ntr = (np.arange(first, first + n) %% 5 + 1)
 red = sharding.reduce_summary(sharding.local_summary(cost, descent, ntr))
-np.save(os.path.join(os.environ["OUT"], "r%%d.npy" %% rank), np.concatenate([red, [first, n]]))
-dist.destroy_process_group()
+# the same through torch tensors (what bench.py hands over) and the max-reduction of the timing
+redt = sharding.reduce_summary(sharding.local_summary(torch.from_numpy(cost), torch.from_numpy(descent), torch.from_numpy(ntr)))
+tmax = sharding.all_reduce(np.array([1.0 + rank]), "max")
+np.save(os.path.join(os.environ["OUT"], "r%%d.npy" %% rank), np.concatenate([red, redt.numpy(), tmax, [first, n]]))
+torch.distributed.destroy_process_group()
 '''
 
 
 def test_two_rank_gloo_reduction_equals_single_process(tmp_path):
     """8(e): shard the batch over 2 ranks, reduce the scalar summary with one all-reduce, and compare
-    with the single-process sum over the whole batch."""
+    with the single-process sum over the whole batch.  (The same functions carry bench.py; two ranks through the
+    real solver: tests/test_gpu_multirank.py.)"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
     env = dict(os.environ, OUT=str(tmp_path), MASTER_ADDR="127.0.0.1")
@@ -86,8 +90,9 @@ def test_two_rank_gloo_reduction_equals_single_process(tmp_path):
                            "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)], env=env,
                           timeout=300)
     r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
-    assert np.array_equal(r0[:5], r1[:5])                 # both ranks hold the reduced vector
-    assert (r0[5], r0[6], r1[5], r1[6]) == (0, 501, 501, 500)
+    assert np.array_equal(r0[:11], r1[:11])               # both ranks hold the reduced vectors
+    assert np.array_equal(r0[:5], r0[5:10]) and r0[10] == 2.0
+    assert (r0[11], r0[12], r1[11], r1[12]) == (0, 501, 501, 500)
     B = 1001
     x0 = problems.random_x0(B, seed=20260403, first=0)
     cost = x0[:, 2] ** 2 + x0[:, 0]
@@ -95,3 +100,12 @@ def test_two_rank_gloo_reduction_equals_single_process(tmp_path):
     ref = sharding.local_summary(cost, -np.abs(x0[:, 4]), np.arange(B) % 5 + 1)
     assert np.allclose(r0[:5], ref, rtol=1e-13, atol=0)
     assert r0[3] == B and r0[4] == 1
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """bench.py --gpus N must run N ranks: under a launcher with another WORLD_SIZE it exits non-zero instead of
+    printing a line for the wrong rank count (no GPU is touched before that check)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()

@@ -19,7 +19,7 @@ for kk in range(N):
     torch.cuda.synchronize()
     sc = s.scalars()
     st = sc["status"]
-    ms = [round(ev[i].elapsed_time(ev[i + 1]), 3) for i in range(3)]
+    ms = [round(ev[i].elapsed_time(ev[i + 1]), 3) for i in range(2)] + [round(ev[2].elapsed_time(ev[4]), 3)]
     tot += sum(ms)
     print(kk, "ms", ms, "exhausted", int((st & 16 != 0).sum()), "mean trials", round(float(sc["ntrials"].mean()), 2))
 print("mean ms per iteration", round(tot / N, 3))
