@@ -53,7 +53,7 @@ class Problem(C.Structure):
 class Params(C.Structure):
     _fields_ = [("max_iters", C.c_int32), ("armijo_maxiters", C.c_int32), ("stepsize_0", C.c_double),
                 ("cc", C.c_double), ("beta", C.c_double), ("term_cond", C.c_double),
-                ("hessian_switch", C.c_int32), ("overlap", C.c_int32)]
+                ("hessian_switch", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Tuning(C.Structure):
@@ -83,6 +83,7 @@ SYMBOLS = {
     "aoc_initial_trajectory": (C.c_int, [_P, _D, _D, _P, _P, _P]),
     "aoc_rollout_cost": (C.c_int, [_P] * 9),
     "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
+    "aoc_gradient": (C.c_int, [_P] * 7),
     "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 8),
     "aoc_linesearch_scratch_bytes": (_Z, [_I, _I]),
     "aoc_spec_max": (_I, []),
@@ -93,7 +94,6 @@ SYMBOLS = {
     "aoc_lqr_tracking": (C.c_int, [_P] * 9),
     "aoc_ltv_lqr": (C.c_int, [_I, _I, _I] + [_P] * 17),
     "aoc_workspace_bytes": (_Z, [_I, _I]),
-    "aoc_overlap_split": (_I, [_I]),
     "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 12),
     "aoc_solve_workspace_bytes": (_Z, [_I, _I]),
     "aoc_newton_solve": (C.c_int, [_P] * 6 + [_I] + [_P] * 10),

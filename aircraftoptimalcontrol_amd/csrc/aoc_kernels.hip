@@ -270,6 +270,10 @@ int aoc_backward(const aoc_problem* p, int32_t full_hessian, const void* x, cons
                  double* Kt, double* lmbd0, int32_t* status) {
     return aoc64::api_backward(p, full_hessian, x, u, x0, Kt, lmbd0, status);
 }
+int aoc_gradient(const aoc_problem* p, const void* x, const double* u, const double* x0, double* du, double* slope,
+                 int32_t* status) {
+    return aoc64::api_gradient(p, x, u, x0, du, slope, status);
+}
 int aoc_forward(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const void* x, const double* u,
                 const double* x0, const double* Kt, double* du, double* descent, double* J_trial, int32_t* status) {
     return aoc64::api_forward(p, prm, n_spec, x, u, x0, Kt, du, descent, J_trial, status);
@@ -301,7 +305,6 @@ int aoc_ltv_lqr(int32_t nb, int32_t T, int32_t augmented, const double* A, const
     return aoc64::api_ltv_lqr(nb, T, augmented, A, Bm, Q, R, S, Qf, x0, q, r, qf, KK, PP, xx, uu, nreg, nsing, stream);
 }
 size_t aoc_workspace_bytes(int32_t B, int32_t T) { return aoc64::api_workspace_bytes(B, T); }
-int32_t aoc_overlap_split(int32_t B) { return B >= 1 ? aoc64::overlap_split_tiles(B) : 0; }
 int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, const void* x, const double* u,
                        const double* x0, const double* J_cur, void* workspace, void* x_new, double* u_new,
                        double* J_new, double* descent, double* stepsize, int32_t* ntrials, int32_t* status) {

@@ -8,7 +8,7 @@ Same constructor arguments, method names, return values and stdout lines as the 
 anything else raises TypeError.  Differences, all outside the numerical path: no Matplotlib figures
 are opened (histories are kept on the object instead: `.JJ`, `.descent`, `.stepsizes`), and
 `GradientMethod.optimize`, which raises TypeError in the reference (8 arguments passed to a
-9-parameter method, optcon.py:125 vs :204), raises NotImplementedError here.
+9-parameter method, optcon.py:125 vs :204), runs here with the missing argument supplied (parity unpinned).
 """
 import numpy as np
 
@@ -56,8 +56,31 @@ class GradientMethod:
                               armijo_maxiters=self.armijo_maxiters, term_cond=-1e-6)
 
     def optimize(self, xx_init, uu_init, tf, dt):
-        raise NotImplementedError("GradientMethod.optimize is unusable in the reference (TypeError at optcon.py:125); "
-                                  "use NewtonMethod")
+        """-> xx_star (ns,TT), uu_star (ni,TT)   (optcon.py:27-174): steepest descent.  In the reference this method
+        raises TypeError (armijo_stepsize is called with 8 of its 9 arguments, :125 vs :204); here the loop runs with the
+        missing JP = JJ[kk] supplied and the directional derivative -descent[kk] as the Armijo slope.  Same stdout line
+        per iteration, same stopping rule (descent <= 1e-6, the constructor's term_cond ignored, :52) and returned
+        iterate (index kk-1 on convergence, :137-140).  Parity unpinned: checked against the oracle's restatement."""
+        TT = int(tf / dt)                                   # optcon.py:43
+        prob = self._problem(TT)
+        prm = self._params()
+        s = _b.GradientBatchSolver(prob, 1, prm)
+        s.set_initial(np.asarray(xx_init, dtype=np.float64)[None, :, :TT], np.asarray(uu_init, dtype=np.float64)[None, :, :TT])
+        print('-*-*-*-*-*-')                                # optcon.py:81
+        exhausted = self.stepsize_0
+        for _ in range(int(self.armijo_maxiters)):
+            exhausted = self.beta * exhausted
+
+        def echo(kk, sc):
+            if float(sc["stepsize"][0]) != exhausted:
+                print('Armijo stepsize = {}'.format(float(sc["stepsize"][0])))   # optcon.py:272
+            print('Iter = {}\t Descent = {}\t Cost = {}'.format(kk, -float(sc["descent"][0]), float(sc["cost"][0])))   # :143
+
+        r = s.solve(callback=echo)
+        h = r["history"]
+        self.JJ, self.descent, self.stepsizes = h["cost"][0], -h["descent"][0], h["stepsize"][0]
+        self.iters, self.status = int(r["iters"][0]), int(r["status"][0])
+        return r["xx_star"][0], r["uu_star"][0]
 
     def get_update(self, stepsize, uu, deltau, x0):
         """-> xx_temp (ns,TT), uu_temp (ni,TT)   (optcon.py:176-200)"""

@@ -12,8 +12,8 @@ with tf = 1, dt = 2e-3 (T = 500), fp64, random x0 keyed by the global trajectory
 131 072 trajectories per GPU (2^20 over the 8 GPUs of a node; weak scaling: per-GPU work is fixed).  One "step" =
 one full Newton iteration (backward Riccati pass, forward LQR pass with the first Armijo trials, Armijo
 back-tracking, update) of every trajectory of the shard; the timed region runs iterations kk = 0..K-1 from the
-initial guess with inputs resident in HBM, exactly as a user would (`aoc_newton_iterate`, two staggered half
-batches on two streams unless --no-overlap).  No data-path collective; one all-reduce of five scalars (RCCL for
+initial guess with inputs resident in HBM (`aoc_newton_iterate` per iteration; the shard as two half batches on two
+HIP streams that never wait for each other, unless --no-overlap).  No data-path collective; one all-reduce of five scalars (RCCL for
 N > 1) closes the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline`/`kernels` come from HIP events recorded on the launch stream between the
@@ -169,12 +169,12 @@ def run(a):
     assert n_own == Bg
     x0 = problems.random_x0(Bg, seed=20260403, first=first)            # synthetic inputs of this rank's shard
     bp = batch.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt, device=dev)
-    mk = lambda ov: batch.make_params(max_iters=200, stepsize_0=1.0, cc=0.5, beta=0.7, armijo_maxiters=10, overlap=ov)
-    overlap = not a.no_overlap
-    prm = mk(int(overlap))
-    s = batch.NewtonBatchSolver(bp, Bg, prm)
+    prm = batch.make_params(max_iters=200, stepsize_0=1.0, cc=0.5, beta=0.7, armijo_maxiters=10)
+    s = batch.NewtonBatchSolver(bp, Bg, prm)       # one stream: the attribution pass, or everything with --no-overlap
+    # two half batches on two streams pay while each half is still a large-batch launch (one wavefront per tile kernels)
+    overlap = not a.no_overlap and s.nt >= 2048
+    s2 = batch.TwoStreamNewtonSolver(bp, Bg, prm) if overlap else None
     x0d = torch.from_numpy(x0).to(dev)
-    overlap = overlap and bool(s.overlap_active())
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -182,34 +182,37 @@ def run(a):
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    def summary():
+    def summary(sv):
         """scalar summary of the shard + the path's only collective (RCCL for N > 1)"""
-        return sharding.reduce_summary(sharding.local_summary(s.J[s.jcur][:Bg], s.descent[:Bg], s.ntrials[:Bg]))
+        return sharding.reduce_summary(sharding.local_summary(*sv.summary_tensors()))
 
-    def timed_region(step):
-        s.set_initial_from_x0(x0d)
+    def timed_region(sv, step):
+        sv.set_initial_from_x0(x0d)
         barrier()
         t0 = time.perf_counter()
         evs = [step(k) for k in range(K)]
-        summ = summary()
+        summ = summary(sv)
         barrier()
         el = time.perf_counter() - t0
         return float(sharding.all_reduce(torch.tensor([el], dtype=torch.float64, device=dev), "max").item()), summ, evs
 
     # warmup: W iterations from the initial guess (and one summary, so that no lazily loaded code object is first
     # touched inside the timed region), then reset: the timed region is exactly iterations 0..K-1 of the solve
-    s.set_initial_from_x0(x0d)
-    for k in range(a.warmup):
-        s.iterate(k) if overlap else s.iterate_timed(k)
-    summary()
+    for sv in ([s2, s] if overlap else [s]):
+        sv.set_initial_from_x0(x0d)
+        for k in range(a.warmup):
+            sv.iterate(k)
+        summary(sv)
+    s.iterate_timed(0)
     if overlap:
-        el, summ, _ = timed_region(lambda k: s.iterate(k))
-        _, _, evs = timed_region(lambda k: s.iterate_timed(k))         # attribution: same iterations, one stream
+        el, summ, _ = timed_region(s2, lambda k: s2.iterate(k))
+        _, _, evs = timed_region(s, lambda k: s.iterate_timed(k))      # attribution: same iterations, one stream
     else:
-        el, summ, evs = timed_region(lambda k: s.iterate_timed(k))
-    sc = s.scalars()
+        el, summ, evs = timed_region(s, lambda k: s.iterate_timed(k))
+    res = s2 if overlap else s
+    sc = res.scalars()
     if os.environ.get("AOC_BENCH_DUMP"):   # tests: this rank's per-trajectory results after the K iterations
-        xx, uu = s.current()
+        xx, uu = res.current()
         np.savez(os.path.join(os.environ["AOC_BENCH_DUMP"], "rank%d_of_%d.npz" % (rank, world)), first=first, xx=xx, uu=uu,
                  summary=summ.cpu().numpy(), **sc)
 
@@ -255,7 +258,7 @@ def run(a):
                                "nobody is stopped, so from kk~13 a third of the trajectories exhausts every line search)"
                                % (T, pr.dt, Bg, K - 1, int((~full).sum()), int(full.sum())),
                    "batch_per_gpu": Bg, "global_batch": Bg * world, "T": T, "parallelism": "batch-sharded x%d" % world,
-                   "streams": "two staggered half batches (aoc_params.overlap)" if overlap else "one",
+                   "streams": "two half batches on two HIP streams (batch.TwoStreamNewtonSolver)" if overlap else "one",
                    "armijo": {"stepsize_0": 1.0, "cc": 0.5, "beta": 0.7, "maxiters": 10}},
         "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["algorithmic_GBps"], "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": dom["frac_algorithmic"], "traffic": dom["traffic"],
@@ -279,7 +282,7 @@ def run(a):
         try:
             it = min(K, 10)
             out["cpu_baseline"], sample = cpu_baseline(pr, x0, it)
-            out["rel_err_vs_oracle"] = rel_err_vs_oracle(batch, bp, mk(0), x0, sample, it)
+            out["rel_err_vs_oracle"] = rel_err_vs_oracle(batch, bp, prm, x0, sample, it)
         except Exception as e:  # the baseline is a report, never a reason to lose the bench line
             out.setdefault("cpu_baseline", None)
             out["cpu_baseline_error"] = repr(e)

@@ -3,7 +3,7 @@
 same problem, same solver settings, same artefacts (Data/xx_star*.npy, Data/uu_star*.npy: (6,T)/(2,T)
 float64 C-order), no cvxpy, no Matplotlib.
 
-    python examples/run_newton.py step      [--out Data] [--dt 1e-3]
+    python examples/run_newton.py step      [--out Data] [--dt 1e-3] [--init fixture.npz]
     python examples/run_newton.py acrobatic [--out Data]
 """
 import argparse
@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--out", default="Data")
     ap.add_argument("--tf", type=float, default=1.0)
     ap.add_argument("--dt", type=float, default=1e-3)
+    ap.add_argument("--init", default=None, help=".npz with xx_init (6,T), uu_init (2,T) instead of the P-controller guess")
     a = ap.parse_args()
     pr = problems.step_maneuver(a.tf, a.dt) if a.problem == "step" else problems.acrobatic(a.tf, a.dt)
     dyn = Dynamics()
@@ -31,7 +32,11 @@ def main():
     cst = Cost(pr.QQt, pr.RRt, pr.QQT)
     NM = NewtonMethod(dyn, cst, pr.xx_ref, pr.uu_ref, max_iters=200, stepsize_0=1, cc=0.5, beta=0.7,
                       armijo_maxiters=10, term_cond=1e-6)            # main_newton_method.py:32-42, :160-163
-    xx_init, uu_init = dyn.get_initial_trajectory(pr.xx_ref, pr.tt)  # :170
+    if a.init:
+        g = np.load(a.init, allow_pickle=False)
+        xx_init, uu_init = g["xx_init"], g["uu_init"]
+    else:
+        xx_init, uu_init = dyn.get_initial_trajectory(pr.xx_ref, pr.tt)  # :170
     xx_star, uu_star = NM.optimize(xx_init, uu_init, a.tf, a.dt)     # :179
     os.makedirs(a.out, exist_ok=True)
     suffix = "" if a.problem == "step" else "_acrobatic"

@@ -99,11 +99,7 @@ typedef struct aoc_params {
     double beta;             /* optcon.py:229 */
     double term_cond;        /* -1e-6 hard-coded at optcon.py:368 (constructor value is ignored) */
     int32_t hessian_switch;  /* 8: full Hessian when kk > 8, optcon.py:443 */
-    int32_t overlap;         /* scheduling, not in the reference: 1 = aoc_newton_iterate (and what is built on it) runs a
-                                large batch as two half batches, the second on a library-owned stream started when the
-                                first half's backward pass is done, so that one half streams through HBM while the other
-                                sits in its latency-bound line-search rounds; the caller's stream waits for both before
-                                the call's work counts as done.  Results are identical to overlap = 0. */
+    int32_t reserved;
 } aoc_params;
 
 /* Scheduling knobs.  They select kernel variants and launch shapes only — results never depend on them
@@ -188,6 +184,16 @@ int aoc_rollout_cost(const aoc_problem *prob, const double *x0, const double *u,
 int aoc_backward(const aoc_problem *prob, int32_t full_hessian, const void *x, const double *u,
                  const double *x0, double *Kt, double *lmbd0, int32_t *status);
 
+/* Descent direction of GradientMethod.optimize (optcon.py:101-123): the costate sweep lambda_t = A^T lambda_{t+1} + l_x
+ * from lambda_{T-1} = grad l_T and du_t = -(B_t^T lambda_{t+1} + l_u); du tiled C=2 (sample T-1 zero).
+ * slope[b] = -sum_t |du_t|^2, the directional derivative of the cost along du — the `descent` argument aoc_linesearch
+ * expects (the reference accumulates +sum |du_t|^2 under that name, :123, prints it and stops when it is <= 1e-6).
+ * One steepest-descent iteration = aoc_gradient + aoc_linesearch with n_spec = 0 (J_trial = NULL).  The reference's
+ * own GradientMethod.optimize cannot run (it calls armijo_stepsize with 8 of its 9 arguments, optcon.py:125 vs :204 —
+ * TypeError): this is that loop with the missing JP = JJ[kk] supplied, parity unpinned (oracle restatement only). */
+int aoc_gradient(const aoc_problem *prob, const void *x, const double *u, const double *x0, double *du,
+                 double *slope, int32_t *status);
+
 /* Forward pass: closed-loop linear rollout of ltv_LQR (optcon.py:756-762) giving du; the descent
  *   sum_t (B_t^T lambda_{t+1} + r_t)^T du_t   (optcon.py:474-477)
  * evaluated through the adjoint identity  sum_t (q_t^T dx_t + r_t^T du_t) + q_f^T dx_{T-1}  (same number,
@@ -203,7 +209,8 @@ int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, 
 
 /* Armijo back-tracking (optcon.py:243-273) and the final update (optcon.py:488-491).
  * Trial ii uses alpha_ii = stepsize_0*beta^ii and is accepted iff J'(alpha_ii) <= J_cur +
- * cc*alpha_ii*descent; trials 0..n_spec-1 are judged from J_trial (written by aoc_forward).
+ * cc*alpha_ii*descent; trials 0..n_spec-1 are judged from J_trial (written by aoc_forward; n_spec = 0: none,
+ * J_trial may be NULL).
  * Trajectories still rejected search on: small batches in rounds over a compacted list, several
  * candidate steps of each at once when few remain; large batches through a work list of (trajectory,
  * up to four consecutive candidates) items, a lane carrying the rollouts of its candidates side by side
@@ -263,9 +270,6 @@ int aoc_ltv_lqr(int32_t nb, int32_t T, int32_t augmented, const double *A, const
  * Iteration level.  Workspace: caller-allocated device memory of aoc_workspace_bytes(B,T) bytes.
  * --------------------------------------------------------------------------------------------- */
 size_t aoc_workspace_bytes(int32_t B, int32_t T);
-/* Tiles of the first half when aoc_params.overlap = 1 cuts a batch of B trajectories in two; 0 = the batch is too
- * small to be cut (its halves would no longer be large-batch launches) and overlap has no effect. */
-int32_t aoc_overlap_split(int32_t B);
 
 /* One outer iteration kk of NewtonMethod.optimize for every trajectory (optcon.py:415-491, steps
  * A-G of SURVEY 3.2): backward, forward, line search.  (x,u) current iterate, J_cur its cost

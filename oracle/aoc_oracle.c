@@ -606,6 +606,61 @@ int orc_newton_optimize(const orc_problem *p, const orc_params *prm, const doubl
     return nsing;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * One outer iteration of GradientMethod.optimize (optcon.py:86-136), steepest descent.
+ * PARITY UNPINNED: the reference's own method raises TypeError at optcon.py:125 (it calls armijo_stepsize with 8 of
+ * the 9 arguments of optcon.py:204), so no golden vector exists.  This restates the loop with the one repair that
+ * lets it run: JP = JJ[kk] is passed, and the slope handed to armijo_stepsize is the directional derivative
+ * -descent[kk] (the reference accumulates descent[kk] = +sum |deltau_t|^2, :123; armijo_stepsize's test
+ * J' > JP + cc*stepsize*descent, :268, needs the negative quantity, as NewtonMethod passes it).
+ * out: xx_new, uu_new; JJ, descent (= sum |deltau|^2, what the reference prints), stepsize, ntrials; du (2,T) optional.
+ * ------------------------------------------------------------------------------------------ */
+void orc_gradient_iterate(const orc_problem *p, const orc_params *prm, const double *xx, const double *uu,
+                          const double *x0, double *xx_new, double *uu_new, double *JJ_out, double *descent_out,
+                          double *stepsize_out, int *ntrials_out, double *du_out) {
+    const orc_mark mark_ = arena_mark();
+    const int T = p->T;
+    double *lm = (double *)arena_calloc((size_t)T * 6, sizeof(double));
+    double *du = (double *)arena_calloc((size_t)T * 2, sizeof(double));
+    double *wx = (double *)arena_calloc((size_t)T * 6, sizeof(double));
+    double *wu = (double *)arena_calloc((size_t)T * 2, sizeof(double));
+    double x[6], u[2], xr[6], ur[2], a[6], b[2], fx[36], fu[12];
+    const double JJ = orc_traj_cost(p, xx, uu);                             /* :88-96 */
+    for (int c = 0; c < 6; c++) { x[c] = xx[c * T + T - 1]; xr[c] = p->xx_ref[c * T + T - 1]; }
+    orc_termcost(p, x, xr, a);                                              /* :101-102 */
+    for (int c = 0; c < 6; c++) lm[(T - 1) * 6 + c] = a[c];
+    double descent = 0.0;
+    for (int t = T - 2; t >= 0; t--) {                                      /* :104-123 */
+        for (int c = 0; c < 6; c++) { x[c] = xx[c * T + t]; xr[c] = p->xx_ref[c * T + t]; }
+        for (int c = 0; c < 2; c++) { u[c] = uu[c * T + t]; ur[c] = p->uu_ref[c * T + t]; }
+        orc_stagecost(p, x, u, xr, ur, a, b);
+        orc_step(&p->mdl, x, u, NULL, NULL, fx, fu, NULL, NULL, NULL, NULL, NULL);
+        /* lmbd_t = AA.T @ lmbd_{t+1} + aa with AA.T = fx (:114); deltau_t = -BB.T @ lmbd_{t+1} - bb with BB.T = fu (:115) */
+        for (int i = 0; i < 6; i++) {
+            double s = 0.0;
+            for (int k = 0; k < 6; k++) s += fx[i * 6 + k] * lm[(t + 1) * 6 + k];
+            lm[t * 6 + i] = s + a[i];
+        }
+        double d[2];
+        for (int i = 0; i < 2; i++) {
+            double s = 0.0;
+            for (int k = 0; k < 6; k++) s += (-fu[i * 6 + k]) * lm[(t + 1) * 6 + k];
+            d[i] = s - b[i];
+            du[i * T + t] = d[i];
+        }
+        descent += d[0] * d[0] + d[1] * d[1];                              /* :123 */
+    }
+    int ntr = 0;
+    const double stepsize = orc_armijo(p, prm, uu, du, x0, -descent, JJ, &ntr, wx, wu);   /* :125, repaired */
+    orc_get_update(p, stepsize, uu, du, x0, xx_new, uu_new);                /* :131-134 */
+    if (JJ_out) *JJ_out = JJ;
+    if (descent_out) *descent_out = descent;
+    if (stepsize_out) *stepsize_out = stepsize;
+    if (ntrials_out) *ntrials_out = ntr;
+    if (du_out) memcpy(du_out, du, (size_t)T * 2 * sizeof(double));
+    arena_release(mark_);
+}
+
 /* Dynamics.get_initial_trajectory (aircraft_simplified.py:126-148): P-controller rollout.
    xx_ref_b (6,T): reference whose column 0 is the start state. */
 void orc_initial_trajectory(const orc_model *md, int T, const double *xx_ref, double *xx, double *uu) {

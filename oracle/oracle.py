@@ -163,6 +163,17 @@ def newton_iterate(prob, prm, kk, xx, uu, x0, want_internals=False):
     return out
 
 
+def gradient_iterate(prob, prm, xx, uu, x0):
+    """One iteration of GradientMethod.optimize with the missing JP argument supplied (parity unpinned: the
+    reference's method raises TypeError)."""
+    T = prob.T
+    xn = np.zeros((6, T)); un = np.zeros((2, T)); du = np.zeros((2, T))
+    J = C.c_double(); d = C.c_double(); s = C.c_double(); ntr = C.c_int()
+    lib().orc_gradient_iterate(C.byref(prob.c), C.byref(prm), _p(_f64(xx)), _p(_f64(uu)), _p(_f64(x0)), _p(xn), _p(un),
+                               C.byref(J), C.byref(d), C.byref(s), C.byref(ntr), _p(du))
+    return dict(xx=xn, uu=un, J=J.value, descent=d.value, stepsize=s.value, ntrials=ntr.value, du=du)
+
+
 def newton_optimize(prob, prm, xx_init, uu_init):
     T = prob.T
     xs = np.zeros((6, T)); us = np.zeros((2, T))

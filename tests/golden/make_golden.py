@@ -10,7 +10,7 @@ only.  The driver scripts themselves are NOT imported (they need cvxpy and call
 plt.show/np.save at import); the problem set-up they do is re-stated below from
 main_newton_method.py:32-142 and acrobatic_newton.py:34-154.
 
-Run:  MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+Run:  MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py [config1]
 """
 import contextlib
 import io
@@ -237,7 +237,30 @@ def lqr_case(p, xx, uu, full_hessian):
                 n_regularised=np.int64(nreg["n"]))
 
 
+def full_solve(p, name):
+    """G8: NewtonMethod(max_iters=200).optimize to its own termination — iteration count, Armijo steps and trial
+    counts, stdout scalars, the returned iterate (index n_done-2, Q7) and its neighbours."""
+    xi, ui = p["dyn"].get_initial_trajectory(p["xx_ref"], p["tt"])
+    full, its = run_newton(p, xi, ui, 199, ())
+    nd = int(full["n_done"])
+    for k in (nd - 2, nd - 1, nd):
+        if 1 <= k <= len(its):
+            full["xx_it%d" % k], full["uu_it%d" % k] = its[k - 1]
+    save(name, **full)
+    print("full solve %s: iterations printed = %d, cost %r -> %r, ntrials %s" %
+          (name, nd, float(full["cost"][0]), float(full["cost"][-1]), full["ntrials"].tolist()))
+
+
+def config1_full_solves():
+    """BASELINE configs[0] / SURVEY 8d config 1: the two drivers of the reference at their native T = 1000
+    (main_newton_method.py:32-142: 23 iterations, returned iterate 21; acrobatic_newton.py:34-154: 37 iterations)."""
+    full_solve(step_problem(), "g8_full_step_T1000")
+    full_solve(acro_problem(), "g8_full_acro_T1000")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "config1":   # only the fixtures added in round 2
+        return config1_full_solves()
     rng = np.random.default_rng(20260331)
 
     # ---------------- G1: Dynamics.step unit vectors ----------------
@@ -358,6 +381,7 @@ def main():
         r, its = run_newton(p5, XI[b], UI[b], nit, ())
         XO[b], UO[b] = its[nit - 1]
         CO[b], DE[b], ST[b] = r["cost"], r["descent"], r["stepsize"]
+    config1_full_solves()
     save("g9_minibatch_step_T500", x0=x0s, xx_init=XI, uu_init=UI, xx_out=XO.astype(np.float32),
          x0_out=XO[:, :, 0].copy(), uu_out=UO, cost=CO, descent=DE, stepsize=ST, n_iters=np.int64(nit))
 

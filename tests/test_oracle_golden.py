@@ -117,18 +117,32 @@ def test_g6_chain_free_running(chain, prob):
             assert rel_err(uu, g["uu_it%d" % (kk + 1)], 1e-3) < 1e-8, kk
 
 
-def test_g8_full_solve_return_index():
-    """Full solve to convergence: 22 iterations, returned iterate is index n_done-2 (Q7) with
-    uu[:,-1] = uu[:,-2] (Q8)."""
-    g = load_golden("g8_full_step_T500")
-    _, p = _prob("problem_step_T500")
+G8 = [("g8_full_step_T500", "problem_step_T500", 22), ("g8_full_step_T1000", "problem_step_T1000", 23),
+      ("g8_full_acro_T1000", "problem_acro_T1000", 37)]
+
+
+def oracle_matches_g8_history(r, g):
+    """How far the oracle's Armijo history equals the reference's: n if identical."""
+    n = min(len(r["stepsize"]), len(g["stepsize"]))
+    same = (r["stepsize"][:n] == g["stepsize"][:n]) & (r["ntrials"][:n] == g["ntrials"][:n])
+    return n if same.all() and len(r["stepsize"]) == len(g["stepsize"]) else int(np.argmin(same))
+
+
+@pytest.mark.parametrize("name,prob,n_ref", G8)
+def test_g8_full_solve_return_index(name, prob, n_ref):
+    """Full solves to the reference's own termination (configs[0]: main_newton_method.py 23 iterations at T = 1000,
+    acrobatic_newton.py 37; and the T = 500 variant, 22): iteration count, returned iterate = index n_done-2 (Q7) with
+    uu[:,-1] = uu[:,-2] (Q8), exhausted line searches (Q5) at the recorded iterations."""
+    g = load_golden(name)
+    _, p = _prob(prob)
     prm = orc.params(max_iters=200)
     r = orc.newton_optimize(p, prm, g["xx_init"], g["uu_init"])
     n = int(g["n_done"])
+    assert n == n_ref
+    assert (g["ntrials"] == 10).sum() >= 3          # the reference exhausts its line search several times (Q5)
+    assert oracle_matches_g8_history(r, g) == n, "Armijo history leaves the reference's at iteration %d" % oracle_matches_g8_history(r, g)
     assert r["iters"] == n
     assert r["ret_index"] == n - 2
-    assert np.array_equal(r["ntrials"], g["ntrials"])
-    assert np.array_equal(r["stepsize"], g["stepsize"])
     assert np.allclose(r["cost"], g["cost"], rtol=1e-9, atol=0)
     # late iterations sit in fp32 rounding noise (SURVEY 8c): descent ~1e-6 compared loosely there
     assert np.allclose(r["descent"], g["descent"], rtol=1e-6, atol=1e-9)
@@ -162,3 +176,25 @@ def test_g9_minibatch():
     assert np.allclose(r["descent"], g["descent"], rtol=1e-8, atol=0)
     assert np.array_equal(xx[:, :, 1:].astype(np.float32), g["xx_out"][:, :, 1:])
     assert rel_err(uu, g["uu_out"], 1e-3) < 1e-8
+
+
+def test_gradient_method_restatement_descends():
+    """GradientMethod.optimize (optcon.py:27-174) restated with the missing JP argument: PARITY UNPINNED (the
+    reference's method raises TypeError, optcon.py:125 vs :204; no golden vector can exist).  Sanity only: the
+    direction is the negative gradient, every accepted step satisfies the Armijo inequality, the cost decreases."""
+    g, p = _prob("problem_step_T500")
+    c = load_golden("g6_chain_step_T500")
+    prm = orc.params(stepsize_0=1e-1, armijo_maxiters=20)
+    xx, uu = c["xx_init"], c["uu_init"]
+    J = []
+    for k in range(5):
+        r = orc.gradient_iterate(p, prm, xx, uu, xx[:, 0])
+        assert r["descent"] > 0 and abs(r["descent"] - (r["du"] ** 2).sum()) <= 1e-12 * r["descent"]
+        xt, ut = orc.get_update(p, 1e-3, uu, r["du"], xx[:, 0])
+        fd = (orc.traj_cost(p, xt, ut) - r["J"]) / 1e-3
+        assert abs(fd + r["descent"]) <= 0.05 * r["descent"]
+        Jn = orc.traj_cost(p, r["xx"], r["uu"])
+        assert r["ntrials"] <= 20 and Jn <= r["J"] - 0.5 * r["stepsize"] * r["descent"]
+        J.append(r["J"])
+        xx, uu = r["xx"], r["uu"]
+    assert abs(J[0] - c["cost"][0]) <= 1e-12 * J[0] and all(b < a for a, b in zip(J, J[1:]))
