@@ -47,7 +47,7 @@ class Model(C.Structure):
 class Problem(C.Structure):
     _fields_ = [("model", Model), ("QQt", C.c_double * 36), ("RRt", C.c_double * 4), ("QQT", C.c_double * 36),
                 ("B", C.c_int32), ("T", C.c_int32), ("x_in_f32", C.c_int32), ("x_out_f32", C.c_int32),
-                ("ref", C.c_void_p), ("stream", C.c_void_p)]
+                ("ref_per_traj", C.c_int32), ("ref_T", C.c_int32), ("ref", C.c_void_p), ("stream", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -58,7 +58,7 @@ class Params(C.Structure):
 
 class Tuning(C.Structure):
     """aoc_tuning (include/aoc.h): scheduling knobs; results never depend on them."""
-    _fields_ = [(n, C.c_int32) for n in ("nspec", "split_tiles", "split_bw_tiles", "ls_dense", "ls_wcap", "ls_kgrow",
+    _fields_ = [(n, C.c_int32) for n in ("nspec", "split_tiles", "split_bw_tiles", "reserved0", "ls_wcap", "ls_kgrow",
                                          "trial_split", "solve_norepack", "ls_worklist", "ls_cpl", "ls_depth_min")] + \
                [("reserved", C.c_int32 * 5)]
 
@@ -148,7 +148,7 @@ class tuning:
         l.aoc_get_tuning(C.byref(self.old))
         new = Tuning.from_buffer_copy(self.old)
         for k, v in self.kw.items():
-            if k not in dict(Tuning._fields_) or k == "reserved":
+            if k not in dict(Tuning._fields_) or k.startswith("reserved"):
                 raise AttributeError("aoc_tuning has no field %r" % k)
             setattr(new, k, int(v))
         l.aoc_set_tuning(C.byref(new))

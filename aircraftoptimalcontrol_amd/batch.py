@@ -47,30 +47,44 @@ def _dev_f64(a, device):
 class BatchProblem:
     """Dynamics constants + Cost weights + reference curves on one GPU.
 
-    Mirrors what NewtonMethod.__init__ captures (reference optcon.py:335-339): the reference curves
-    are shared by every trajectory of the batch."""
+    Mirrors what NewtonMethod.__init__ captures (reference optcon.py:335-339).  xx_ref (6,T) / uu_ref (2,T): one
+    curve shared by every trajectory of the batch (B instances of the same NewtonMethod).  xx_ref (B,6,T) / uu_ref
+    (B,2,T): one curve per trajectory (B NewtonMethod instances with their own references: different manoeuvres in
+    one batch, MPC instances tracking different targets); the batch size is then fixed to B."""
 
     def __init__(self, QQt, RRt, QQT, xx_ref, uu_ref, dt, model=None, device="cuda:0"):
         torch = _torch()
         self.device = torch.device(device)
         xx_ref = np.ascontiguousarray(xx_ref, dtype=np.float64)
         uu_ref = np.ascontiguousarray(uu_ref, dtype=np.float64)
-        if xx_ref.ndim != 2 or xx_ref.shape[0] != 6 or uu_ref.shape != (2, xx_ref.shape[1]):
+        self.per_traj = xx_ref.ndim == 3
+        if self.per_traj:
+            if xx_ref.shape[1] != 6 or uu_ref.shape != (xx_ref.shape[0], 2, xx_ref.shape[2]):
+                raise ValueError("per-trajectory references: xx_ref must be (B,6,T) and uu_ref (B,2,T)")
+        elif xx_ref.ndim != 2 or xx_ref.shape[0] != 6 or uu_ref.shape != (2, xx_ref.shape[1]):
             raise ValueError("xx_ref must be (6,T) and uu_ref (2,T)")
-        self.T = int(xx_ref.shape[1])
+        self.T = int(xx_ref.shape[-1])
         self.QQt = np.ascontiguousarray(QQt, dtype=np.float64).reshape(6, 6)
         self.RRt = np.ascontiguousarray(RRt, dtype=np.float64).reshape(2, 2)
         self.QQT = np.ascontiguousarray(QQT, dtype=np.float64).reshape(6, 6)
         self.model = model if model is not None else default_model(dt)
         self.model.dt = float(dt)
         self.xx_ref, self.uu_ref = xx_ref, uu_ref
-        ref = np.concatenate([xx_ref, uu_ref], axis=0).T.copy()  # [T][8]
-        self.ref = torch.from_numpy(ref).to(self.device)
+        if self.per_traj:
+            self.B_ref = int(xx_ref.shape[0])
+            self.ref = pack(np.concatenate([xx_ref, uu_ref], axis=1), self.device)    # tiled, C = 8
+        else:
+            self.B_ref = None
+            ref = np.concatenate([xx_ref, uu_ref], axis=0).T.copy()  # [T][8]
+            self.ref = torch.from_numpy(ref).to(self.device)
 
     def c_problem(self, B, stream=None, x_in_f32=0, x_out_f32=0):
         torch = _torch()
+        if self.per_traj and int(B) != self.B_ref:
+            raise ValueError("this problem carries %d per-trajectory reference curves; batch of %d asked" % (self.B_ref, B))
         p = Problem()
         p.x_in_f32, p.x_out_f32 = int(x_in_f32), int(x_out_f32)
+        p.ref_per_traj, p.ref_T = int(self.per_traj), 0
         p.model = self.model
         p.QQt[:] = self.QQt.ravel().tolist()
         p.RRt[:] = self.RRt.ravel().tolist()

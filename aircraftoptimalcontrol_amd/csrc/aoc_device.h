@@ -47,6 +47,7 @@ struct KConst {
     real rJ;     // 1/J rounded to nearest (div_by_const)
     real Q[36], R[4], QT[36];
     int T, ntiles, B, diag;  // diag: Q,R,QT all diagonal (every driver of the reference)
+    int rpt, refT;           // reference curves per trajectory (tiled, refT samples each) instead of one shared curve
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -28,6 +28,15 @@ using aoc_common::TILE;
         if (flag) { constexpr bool NAME = true; __VA_ARGS__; } \
         else { constexpr bool NAME = false; __VA_ARGS__; }      \
     } while (0)
+// reference curves shared (false) or per trajectory (true); the float32 build (sizeof(real) == 4, entry points
+// aoc_*_f32) only has the shared form, so that its kernels are not instantiated twice
+#define AOC_DISPATCH_RPT(flag, NAME, ...)                                         \
+    do {                                                                          \
+        if (flag) { constexpr bool NAME = sizeof(real) == 8; __VA_ARGS__; }       \
+        else { constexpr bool NAME = false; __VA_ARGS__; }                        \
+    } while (0)
+#define AOC_DISPATCH_DR(kc, NAME_D, NAME_R, ...) \
+    AOC_DISPATCH_BOOL((kc).diag, NAME_D, AOC_DISPATCH_RPT((kc).rpt, NAME_R, __VA_ARGS__))
 #define AOC_DISPATCH_XT(f32, NAME, ...)               \
     do {                                              \
         if (f32) { using NAME = float; __VA_ARGS__; } \
@@ -94,7 +103,6 @@ static void tuning_defaults(aoc_tuning* t) {
     t->nspec = env("AOC_NSPEC", 0);
     t->split_tiles = env("AOC_SPLIT_TILES", 512);
     t->split_bw_tiles = env("AOC_SPLIT_BW_TILES", 512);
-    t->ls_dense = env("AOC_LS_DENSE", -1);
     t->ls_wcap = env("AOC_LS_WCAP", 0);
     t->ls_kgrow = env("AOC_LS_KGROW", 0);
     t->trial_split = env("AOC_TRIAL_SPLIT", 1);
@@ -120,6 +128,8 @@ static int check_problem(const aoc_problem* p) {
     if (!p) return einval("aoc_problem is NULL");
     if (!p->ref) return einval("aoc_problem.ref (reference curves) is NULL");
     if (p->B < 1 || p->T < 3) return einval("aoc_problem: B = %d, T = %d (need B >= 1, T >= 3)", p->B, p->T);
+    if (p->ref_per_traj && p->ref_T != 0 && p->ref_T < p->T)
+        return einval("aoc_problem: ref_T = %d < T = %d (samples per trajectory of the per-trajectory reference array)", p->ref_T, p->T);
     // R must be symmetric for the 2x2 closed forms used by the gain solve (every driver of the reference uses a
     // diagonal R; the reference itself would accept any R)
     if (p->RRt[1] != p->RRt[2])
@@ -136,8 +146,6 @@ extern "C" size_t aoc_tiled_elems(int32_t B, int32_t T, int32_t C);
 extern "C" size_t aoc_linesearch_scratch_bytes(int32_t B, int32_t T);
 extern "C" int32_t aoc_default_nspec(int32_t B, int32_t armijo_maxiters);
 constexpr int AOC_SPEC_MAX = 15;   // Armijo candidates that may ride along in the forward pass (5 workgroups per tile)
-// tiles of the dense copy the line search may make of its searching trajectories (aoc_passes.inc, k_ls_gather)
-static inline int ls_dense_tiles(int32_t B) { const int nt = (B + 63) / 64; return nt < 256 ? nt : 256; }
 
 #define AOC_ARITH_NS aoc64
 #define AOC_REAL double
@@ -236,12 +244,10 @@ int32_t aoc_default_nspec(int32_t B, int32_t armijo_maxiters) {
 }
 
 size_t aoc_linesearch_scratch_bytes(int32_t B, int32_t T) {
-    const size_t nt = (size_t)aoc_ntiles(B), dt = (size_t)ls_dense_tiles(B);
-    // the fp64 layout bounds the float32 one
+    (void)T;
+    const size_t nt = (size_t)aoc_ntiles(B);
     return align_up(nt * sizeof(unsigned long long), 16) + align_up((nt + 1) * sizeof(int), 16) +
            align_up(nt * TILE * sizeof(int), 16) + align_up(sizeof(aoc64::LsState), 16) +
-           2 * align_up(dt * (size_t)T * 2 * TILE * sizeof(double), 16) + align_up(dt * 6 * TILE * sizeof(double), 16) +
-           2 * align_up(dt * TILE * sizeof(double), 16) + align_up(dt * TILE * sizeof(int), 16) +
            align_up(nt * TILE * aoc64::LS_WL_IPL * sizeof(int2), 16) + align_up(nt * TILE * sizeof(int), 16) +
            align_up(2 * aoc64::LS_WL_ROUNDS * sizeof(int), 16);
 }
@@ -332,19 +338,23 @@ int aoc_mpc_step(const aoc_problem* p_track, const aoc_problem* p_next, const ao
 
 // ---- float32 arithmetic (aoc32): every array, the reference curves and the workspace are float32 ------
 int aoc_traj_cost_f32(const aoc_problem* p, const float* x, const float* u, const float* x0, float* J) {
+    if (p && p->ref_per_traj) return einval("aoc_traj_cost_f32: per-trajectory reference curves exist in the fp64 build only");
     return aoc32::api_traj_cost(p, x, u, x0, J);
 }
 int aoc_initial_trajectory_f32(const aoc_problem* p, double kp, double kt, const float* x0, float* x, float* u) {
+    if (p && p->ref_per_traj) return einval("aoc_initial_trajectory_f32: per-trajectory reference curves exist in the fp64 build only");
     return aoc32::api_initial_trajectory(p, (float)kp, (float)kt, x0, x, u);
 }
 int aoc_rollout_cost_f32(const aoc_problem* p, const float* x0, const float* u, const float* du, const float* alpha,
                          float* x_out, float* u_out, float* J_out, int32_t* status) {
+    if (p && p->ref_per_traj) return einval("aoc_rollout_cost_f32: per-trajectory reference curves exist in the fp64 build only");
     return aoc32::api_rollout_cost(p, x0, u, du, alpha, x_out, u_out, J_out, status);
 }
 size_t aoc_workspace_bytes_f32(int32_t B, int32_t T) { return aoc32::api_workspace_bytes(B, T); }
 int aoc_newton_iterate_f32(const aoc_problem* p, const aoc_params* prm, int32_t kk, const float* x, const float* u,
                            const float* x0, const float* J_cur, void* workspace, float* x_new, float* u_new,
                            float* J_new, float* descent, float* stepsize, int32_t* ntrials, int32_t* status) {
+    if (p && p->ref_per_traj) return einval("aoc_newton_iterate_f32: per-trajectory reference curves exist in the fp64 build only");
     return aoc32::api_newton_iterate(p, prm, kk, x, u, x0, J_cur, workspace, x_new, u_new, J_new, descent, stepsize,
                                      ntrials, status);
 }

@@ -84,8 +84,14 @@ typedef struct aoc_problem {
     int32_t T;        /* samples per trajectory = int(tf/dt), optcon.py:378 (T-1 stages) */
     int32_t x_in_f32; /* element type of the tiled STATE arrays a call reads: 0 = fp64, 1 = float32 */
     int32_t x_out_f32;/* ... and of those it writes (see "State storage" above) */
-    const void *ref;  /* DEVICE, shared by the batch, time-major [T][8]: xx_ref[0..5,t], uu_ref[0..1,t]; fp64
-                       (float32 for the *_f32 entry points) */
+    int32_t ref_per_traj; /* 0: `ref` is ONE curve shared by the batch, time-major [T][8]: xx_ref[0..5,t], uu_ref[0..1,t]
+                             (what NewtonMethod.__init__ captures, optcon.py:335-339, for every trajectory);
+                             1: one curve PER TRAJECTORY (B NewtonMethod instances with their own xx_ref/uu_ref): `ref` is
+                             a tiled array with C = 8 components, elem(b,t,c) at (((b/64)*ref_T + t)*8 + c)*64 + b%64.
+                             fp64 entry points only. */
+    int32_t ref_T;    /* samples per trajectory in a per-trajectory `ref` array (0 = T); > T lets a caller keep a long
+                         curve on the device and pass windows of it by offsetting `ref` by s*8*64 elements */
+    const void *ref;  /* DEVICE; fp64 (float32 for the *_f32 entry points) */
     void *stream;     /* hipStream_t */
 } aoc_problem;
 
@@ -110,7 +116,7 @@ typedef struct aoc_tuning {
     int32_t nspec;          /* AOC_NSPEC        Armijo candidates riding along in the forward pass; 0 = by batch size */
     int32_t split_tiles;    /* AOC_SPLIT_TILES  several wavefronts per tile in forward/final/rollout/gains up to this many tiles (512) */
     int32_t split_bw_tiles; /* AOC_SPLIT_BW_TILES  ... in the backward pass (512) */
-    int32_t ls_dense;       /* AOC_LS_DENSE     round-based line search: dense-copy capacity in wavefronts; -1 = by batch size, 0 = off */
+    int32_t reserved0;
     int32_t ls_wcap;        /* AOC_LS_WCAP      wavefronts a trial round may occupy (0 = 1024) / the first work list may take with every remaining candidate (0 = 2048) */
     int32_t ls_kgrow;       /* AOC_LS_KGROW     round-based line search: growth of the candidates per round; 0 = by batch size */
     int32_t trial_split;    /* AOC_TRIAL_SPLIT  two-wavefront trial kernels for latency-bound rounds (1) */

@@ -45,7 +45,7 @@ def tuned():
     def set_(**kw):
         new = _lib.Tuning.from_buffer_copy(old)
         for k, v in kw.items():
-            assert k in dict(_lib.Tuning._fields_) and k != "reserved", k
+            assert k in dict(_lib.Tuning._fields_) and not k.startswith("reserved"), k
             setattr(new, k, int(v))
         l.aoc_set_tuning(C.byref(new))
         return new

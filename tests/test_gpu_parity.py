@@ -332,7 +332,7 @@ def test_initial_trajectory_on_device(aoc):
         assert rel_err(xx[b], m["xx_init"][b], 1e-2) < 2e-4
 
 
-LS_MODES = {"rounds": dict(ls_worklist=0, ls_dense=0), "rounds-dense": dict(ls_worklist=0, ls_dense=100000),
+LS_MODES = {"rounds": dict(ls_worklist=0), "rounds-wcap8": dict(ls_worklist=0, ls_wcap=8, ls_kgrow=1),
             "worklist-cpl4": dict(ls_worklist=1, ls_cpl=4), "worklist-cpl2": dict(ls_worklist=1, ls_cpl=2),
             "worklist-cpl1-depth1": dict(ls_worklist=1, ls_cpl=1, ls_depth_min=1)}
 
@@ -340,8 +340,8 @@ LS_MODES = {"rounds": dict(ls_worklist=0, ls_dense=0), "rounds-dense": dict(ls_w
 @pytest.mark.parametrize("mode", sorted(LS_MODES))
 def test_linesearch_rounds_vs_oracle(aoc, mode, tuned):
     """A1: every scheduling of the back-tracking — rounds over a compacted list with several candidate steps of
-    one trajectory evaluated at once when few trajectories still search; "dense": the searching trajectories copied
-    into a dense batch and every remaining step tried there; "worklist": (trajectory, up to cpl candidates) items,
+    one trajectory evaluated at once when few trajectories still search (also with a round capacity of 8 wavefronts:
+    four rounds); "worklist": (trajectory, up to cpl candidates) items,
     depth predicted from the previous iteration's trial count — accepts exactly the step and reports exactly the
     trial count of the reference's sequential loop; checked against the oracle's armijo_stepsize on the GPU's own
     iterates, over four iterations."""
