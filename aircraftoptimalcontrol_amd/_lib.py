@@ -47,7 +47,8 @@ class Model(C.Structure):
 class Problem(C.Structure):
     _fields_ = [("model", Model), ("QQt", C.c_double * 36), ("RRt", C.c_double * 4), ("QQT", C.c_double * 36),
                 ("B", C.c_int32), ("T", C.c_int32), ("x_in_f32", C.c_int32), ("x_out_f32", C.c_int32),
-                ("ref_per_traj", C.c_int32), ("ref_T", C.c_int32), ("ref", C.c_void_p), ("stream", C.c_void_p)]
+                ("ref_per_traj", C.c_int32), ("ref_T", C.c_int32), ("x_is_rollout", C.c_int32), ("reserved", C.c_int32),
+                ("ref", C.c_void_p), ("stream", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -59,8 +60,9 @@ class Params(C.Structure):
 class Tuning(C.Structure):
     """aoc_tuning (include/aoc.h): scheduling knobs; results never depend on them."""
     _fields_ = [(n, C.c_int32) for n in ("nspec", "split_tiles", "split_bw_tiles", "reserved0", "ls_wcap", "ls_kgrow",
-                                         "trial_split", "solve_norepack", "ls_worklist", "ls_cpl", "ls_depth_min")] + \
-               [("reserved", C.c_int32 * 5)]
+                                         "trial_split", "solve_norepack", "ls_worklist", "ls_cpl", "ls_depth_min",
+                                         "fw_recompute")] + \
+               [("reserved", C.c_int32 * 4)]
 
 
 # every symbol include/aoc.h declares: (name, restype, argtypes)

@@ -70,6 +70,8 @@ class BatchProblem:
         self.model = model if model is not None else default_model(dt)
         self.model.dt = float(dt)
         self.xx_ref, self.uu_ref = xx_ref, uu_ref
+        self.ref_T = 0          # samples per trajectory of a per-trajectory `ref` array (0 = T) and element offset of
+        self.ref_offset = 0     #  the window in use: a long curve on the device, a window of it per call (mpc.py)
         if self.per_traj:
             self.B_ref = int(xx_ref.shape[0])
             self.ref = pack(np.concatenate([xx_ref, uu_ref], axis=1), self.device)    # tiled, C = 8
@@ -78,19 +80,20 @@ class BatchProblem:
             ref = np.concatenate([xx_ref, uu_ref], axis=0).T.copy()  # [T][8]
             self.ref = torch.from_numpy(ref).to(self.device)
 
-    def c_problem(self, B, stream=None, x_in_f32=0, x_out_f32=0):
+    def c_problem(self, B, stream=None, x_in_f32=0, x_out_f32=0, x_is_rollout=0):
         torch = _torch()
         if self.per_traj and int(B) != self.B_ref:
             raise ValueError("this problem carries %d per-trajectory reference curves; batch of %d asked" % (self.B_ref, B))
         p = Problem()
         p.x_in_f32, p.x_out_f32 = int(x_in_f32), int(x_out_f32)
-        p.ref_per_traj, p.ref_T = int(self.per_traj), 0
+        p.ref_per_traj, p.ref_T = int(self.per_traj), int(self.ref_T)
+        p.x_is_rollout = int(x_is_rollout)
         p.model = self.model
         p.QQt[:] = self.QQt.ravel().tolist()
         p.RRt[:] = self.RRt.ravel().tolist()
         p.QQT[:] = self.QQT.ravel().tolist()
         p.B, p.T = int(B), self.T
-        p.ref = self.ref.data_ptr()
+        p.ref = self.ref.data_ptr() + int(self.ref_offset) * self.ref.element_size()
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         p.stream = s.cuda_stream
         return p
@@ -208,6 +211,7 @@ class NewtonBatchSolver:
         self.ub = [alloc_tiled(B, self.T, 2, dev, zero=True) for _ in range(3)]
         self.x64 = None            # fp64 copy of a caller-supplied initial iterate (only if needed)
         self.cur_is64 = False      # the current iterate is the one in self.x64
+        self.cur_rollout = False   # the current iterate's states are the rollout of its inputs (written by the library)
         self.x_init = None         # (B,6,T) fp64: what set_initial() was given (returned verbatim if a
         self.u_init = None         #  trajectory stops at kk = 1, optcon.py:500-504)
         self.ws = torch.empty((lib().aoc_workspace_bytes(self.B, self.T) + 7) // 8, dtype=torch.float64, device=dev)
@@ -226,7 +230,7 @@ class NewtonBatchSolver:
 
     # -- problem struct with the current stream and the element types of this call's state arrays
     def _p(self, x_in_f32=1, x_out_f32=1):
-        return self.problem.c_problem(self.B, x_in_f32=x_in_f32, x_out_f32=x_out_f32)
+        return self.problem.c_problem(self.B, x_in_f32=x_in_f32, x_out_f32=x_out_f32, x_is_rollout=self.cur_rollout)
 
     def _xin(self):
         """(pointer, is_f32) of the current iterate's state array"""
@@ -250,7 +254,7 @@ class NewtonBatchSolver:
             check(lib().aoc_pack(self.B, self.T, 6, _ptr(xi), _ptr(self.x64), st), "aoc_pack")
         check(lib().aoc_pack_f32(self.B, self.T, 6, _ptr(xi), _ptr(self.xb[0]), st), "aoc_pack_f32")
         check(lib().aoc_pack(self.B, self.T, 2, _ptr(ui), _ptr(self.ub[0]), st), "aoc_pack")
-        self.cur, self.kk, self.jcur = 0, 0, 0
+        self.cur, self.kk, self.jcur, self.cur_rollout = 0, 0, 0, False
         self.status.zero_()
         x, f32 = self._xin()
         p = self._p(f32)
@@ -266,7 +270,7 @@ class NewtonBatchSolver:
         p = self._p()
         check(lib().aoc_initial_trajectory(C.byref(p), float(kp), float(kt), _ptr(self.x0), _ptr(self.xb[0]),
                                            _ptr(self.ub[0])), "aoc_initial_trajectory")
-        self.cur, self.kk, self.jcur = 0, 0, 0
+        self.cur, self.kk, self.jcur, self.cur_rollout = 0, 0, 0, True
         self.status.zero_()
         check(lib().aoc_traj_cost(C.byref(p), _ptr(self.xb[0]), _ptr(self.ub[0]), _ptr(self.x0), _ptr(self.J[0])),
               "aoc_traj_cost")
@@ -283,7 +287,7 @@ class NewtonBatchSolver:
                                        _ptr(self.x0), _ptr(self.J[jc]), _ptr(self.ws), _ptr(self.xb[n]),
                                        _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.descent), _ptr(self.stepsize),
                                        _ptr(self.ntrials), _ptr(self.status)), "aoc_newton_iterate")
-        self.cur, self.jcur, self.kk, self.cur_is64 = n, jn, kk + 1, False
+        self.cur, self.jcur, self.kk, self.cur_is64, self.cur_rollout = n, jn, kk + 1, False, True
 
     PASSES = ("backward", "forward", "linesearch_search", "linesearch_update")
 
@@ -324,7 +328,7 @@ class NewtonBatchSolver:
                                           _ptr(self.xb[n]), _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.stepsize),
                                           _ptr(self.ntrials), _ptr(self.status), _ptr(scratch)), "aoc_linesearch_update")
         ev[4].record(st)
-        self.cur, self.jcur, self.kk, self.cur_is64 = n, jn, kk + 1, False
+        self.cur, self.jcur, self.kk, self.cur_is64, self.cur_rollout = n, jn, kk + 1, False, True
         return ev
 
     # -- results ---------------------------------------------------------------------------------
@@ -387,7 +391,7 @@ class NewtonBatchSolver:
         nw.status[:m] = self.status[:n][keep]
         if self.x_init is not None:
             nw.x_init, nw.u_init = self.x_init[keep], self.u_init[keep]
-        nw.cur, nw.jcur, nw.kk, nw.cur_is64 = 1, 0, self.kk, False
+        nw.cur, nw.jcur, nw.kk, nw.cur_is64, nw.cur_rollout = 1, 0, self.kk, False, True
         return nw
 
     def solve(self, verbose=False, callback=None, compact=True, compact_below=0.5, compact_min=2048):
@@ -560,7 +564,7 @@ class GradientBatchSolver(NewtonBatchSolver):
                                    _ptr(self.J[jc]), _ptr(self.descent), None, _ptr(self.xb[n]), _ptr(self.ub[n]),
                                    _ptr(self.J[jn]), _ptr(self.stepsize), _ptr(self.ntrials), _ptr(self.status),
                                    _ptr(scratch)), "aoc_linesearch")
-        self.cur, self.jcur, self.kk, self.cur_is64 = n, jn, kk + 1, False
+        self.cur, self.jcur, self.kk, self.cur_is64, self.cur_rollout = n, jn, kk + 1, False, True
 
     def direction(self):
         """du (B,2,T) of the last iteration."""

@@ -110,6 +110,7 @@ static void tuning_defaults(aoc_tuning* t) {
     t->ls_worklist = env("AOC_LS_WORKLIST", -1);
     t->ls_cpl = env("AOC_LS_CPL", 1);
     t->ls_depth_min = env("AOC_LS_DEPTH_MIN", 2);
+    t->fw_recompute = env("AOC_FW_RECOMPUTE", 1);
 }
 
 static const aoc_tuning& tuning() {

@@ -28,16 +28,17 @@ TILE = _b.TILE
 
 
 def window(ref_long, s, T):
-    """Reference window [s, s+T) of a (C, >=T) curve, extended by holding its last sample."""
-    n = ref_long.shape[1]
+    """Reference window [s, s+T) of a (C, >=T) curve — or (B, C, >=T) curves —, extended by holding the last sample."""
+    n = ref_long.shape[-1]
     idx = np.minimum(np.arange(s, s + T), n - 1)
-    return ref_long[:, idx]
+    return ref_long[..., idx]
 
 
 class RecedingHorizon:
     def __init__(self, pr, track_weights, B, T, n_newton=2, sigma=None, seed=20260405, device="cuda:0",
                  stepsize_0=1.0, cc=0.5, beta=0.7, armijo_maxiters=10, horizon_steps=4096):
-        """pr: problems.ProblemData (weights + long reference curves xx_ref (6,L), uu_ref (2,L), L >= T);
+        """pr: problems.ProblemData (weights + long reference curves xx_ref (6,L), uu_ref (2,L), L >= T — or
+        (B,6,L), (B,2,L): every instance tracks its own target, aoc_problem.ref_per_traj);
         track_weights: (QQt, RRt, QQT) of the tracking LQR; sigma: (6,) std of the additive state
         disturbance per closed-loop step (None = none); horizon_steps: how many steps the reference curve
         kept on the device is extended for (its last sample is held)."""
@@ -51,9 +52,13 @@ class RecedingHorizon:
                                   armijo_maxiters=armijo_maxiters)
         self.s = 0
         # the whole (extended) reference curve lives on the device once; the window of step s is a pointer offset
-        n_long = max(pr.xx_ref.shape[1], self.T) + int(horizon_steps)
-        self.ref_long = torch.from_numpy(np.concatenate([window(pr.xx_ref, 0, n_long), window(pr.uu_ref, 0, n_long)],
-                                                        axis=0).T.copy()).to(self.device)   # [n_long][8]
+        self.per_traj = np.ndim(pr.xx_ref) == 3
+        n_long = max(pr.xx_ref.shape[-1], self.T) + int(horizon_steps)
+        long8 = np.concatenate([window(pr.xx_ref, 0, n_long), window(pr.uu_ref, 0, n_long)], axis=-2)
+        if self.per_traj:
+            self.ref_long = _b.pack(long8, self.device)                                      # tiled [ntiles][n_long][8][64]
+        else:
+            self.ref_long = torch.from_numpy(long8.T.copy()).to(self.device)                # [n_long][8]
         self.n_long = n_long
         xr, ur = window(pr.xx_ref, 0, T), window(pr.uu_ref, 0, T)
         self.prob = _b.BatchProblem(pr.QQt, pr.RRt, pr.QQT, xr, ur, pr.dt, device=self.device)
@@ -71,9 +76,11 @@ class RecedingHorizon:
         """Point both problems at the reference window [s, s+T) (a view into the device-resident curve)."""
         if s + self.T > self.n_long:
             raise ValueError("reference curve on the device exhausted: raise horizon_steps")
-        view = self.ref_long[s:s + self.T]
-        self.prob.ref = view
-        self.tprob.ref = view
+        for pb in (self.prob, self.tprob):
+            if self.per_traj:   # the whole tiled curve array with its own sample count, the window as an element offset
+                pb.ref, pb.ref_T, pb.ref_offset = self.ref_long, self.n_long, s * 8 * TILE
+            else:
+                pb.ref = self.ref_long[s:s + self.T]
         self.prob.xx_ref, self.prob.uu_ref = window(self.pr.xx_ref, s, self.T), window(self.pr.uu_ref, s, self.T)
 
     def disturbance(self, s):
@@ -115,7 +122,7 @@ class RecedingHorizon:
                                  _b._ptr(sv.descent), _b._ptr(sv.stepsize), _b._ptr(sv.ntrials), _b._ptr(sv.status),
                                  _b._ptr(self.K0_d), _b._ptr(self.ua_d), C.byref(slot)), "aoc_mpc_step")
         sv.cur = a if slot.value == 0 else b
-        sv.jcur, sv.cur_is64, sv.kk = int(slot.value), False, self.n_newton
+        sv.jcur, sv.cur_is64, sv.cur_rollout, sv.kk = int(slot.value), False, True, self.n_newton
         if not fetch:
             self.x_true = None
             return None

@@ -74,13 +74,14 @@ def kernel_names(ntiles, full):
     import ctypes as C
     t = _lib.Tuning()
     _lib.lib().aoc_get_tuning(C.byref(t))
-    fl = "true, true, true" if full else "true, false, false"
+    fl = "true, false, true, true" if full else "true, false, false, false"   # <diagonal weights, shared reference, full Hessian, costate>
     wl = t.ls_worklist > 0 or (t.ls_worklist < 0 and ntiles > t.split_tiles)
+    small = ntiles <= t.split_tiles
     return {
         "backward": ("k_backward2<%s, float>" if ntiles <= t.split_bw_tiles else "k_backward<%s, float>") % fl,
-        "forward": "k_forward_split<true, float>" if ntiles <= t.split_tiles else "k_forward<true, 2, float>",
-        "linesearch_update": "k_ls_final_split<true, float>" if ntiles <= t.split_tiles else "k_ls_final<true, float>",
-        "linesearch_search": ("phase: k_ls_init_wl, k_ls_plan_wl, k_ls_trial_wl<true, %d> x2, k_ls_replan" % max(t.ls_cpl, 1)) if wl
+        "forward": "k_forward_split<true, false, float>" if small else "k_forward<true, false, 2, float>",
+        "linesearch_update": "k_ls_final_split<true, false, float>" if small else "k_ls_final<true, false, float>",
+        "linesearch_search": ("phase: k_ls_init_wl, k_ls_plan_wl, k_ls_trial_wl<true, false, %d> x2, k_ls_replan" % max(t.ls_cpl, 1)) if wl
         else "phase: k_ls_init, k_ls_plan, k_ls_trial*, k_ls_resolve (round-based search)",
     }
 

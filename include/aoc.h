@@ -91,6 +91,12 @@ typedef struct aoc_problem {
                              fp64 entry points only. */
     int32_t ref_T;    /* samples per trajectory in a per-trajectory `ref` array (0 = T); > T lets a caller keep a long
                          curve on the device and pass windows of it by offsetting `ref` by s*8*64 elements */
+    int32_t x_is_rollout; /* 1: the state array a call READS is the rollout of its input array `u` from `x0` as this library
+                             computes it — x_new of aoc_linesearch / aoc_newton_iterate, x_out of aoc_rollout_cost, x of
+                             aoc_initial_trajectory — so a pass that walks forward in time may re-compute the states
+                             instead of reading them (aoc_forward does: 24 B per stage less).  0: arbitrary states (a
+                             caller-supplied initial iterate, optcon.py:395): they are read.  Same results either way. */
+    int32_t reserved;
     const void *ref;  /* DEVICE; fp64 (float32 for the *_f32 entry points) */
     void *stream;     /* hipStream_t */
 } aoc_problem;
@@ -124,7 +130,8 @@ typedef struct aoc_tuning {
     int32_t ls_worklist;    /* AOC_LS_WORKLIST  work-list line search: -1 = above split_tiles tiles, 0 = never, 1 = always */
     int32_t ls_cpl;         /* AOC_LS_CPL       work-list line search: candidate steps per work item / lane (1, 2 or 4; default 1) */
     int32_t ls_depth_min;   /* AOC_LS_DEPTH_MIN work-list line search: candidates tried in the first round at least (2) */
-    int32_t reserved[5];
+    int32_t fw_recompute;   /* AOC_FW_RECOMPUTE aoc_forward re-computes the states when aoc_problem.x_is_rollout allows it (1) */
+    int32_t reserved[4];
 } aoc_tuning;
 void aoc_get_tuning(aoc_tuning *out);
 void aoc_set_tuning(const aoc_tuning *t);

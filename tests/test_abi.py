@@ -34,9 +34,9 @@ def test_geometry_helpers_and_errors():
     assert lib.aoc_workspace_bytes(64, 500) == 64 * 500 * 16 * 8 + lib.aoc_spec_max() * 64 * 8 + lib.aoc_linesearch_scratch_bytes(64, 500)
     assert b"gfx950" in lib.aoc_version()
     assert lib.aoc_strerror(-1) == b"invalid argument"
-    # struct layout must match the header: 9 doubles + 76 doubles + 6 int32 + 2 pointers
+    # struct layout must match the header: 9 doubles + 76 doubles + 8 int32 + 2 pointers
     assert C.sizeof(_lib.Model) == 72
-    assert C.sizeof(_lib.Problem) == 72 + 76 * 8 + 24 + 16
+    assert C.sizeof(_lib.Problem) == 72 + 76 * 8 + 32 + 16
     assert C.sizeof(_lib.Params) == 48
     assert C.sizeof(_lib.Tuning) == 64
     # argument errors are reported before anything touches a device

@@ -633,3 +633,46 @@ def test_split_kernels_equal_single_wavefront_kernels(aoc, tuned):
     for a, b in zip(ha, hb):
         for key in ("stepsize", "ntrials", "cost", "cost_new", "descent", "status"):
             assert np.array_equal(a[key], b[key], equal_nan=True), key
+
+
+def test_forward_state_recomputation_does_not_change_results(aoc, tuned):
+    """aoc_forward re-computes the nominal states x_{t+1} = step(x_t, u_t) instead of reading them when the iterate is a
+    rollout the library wrote (aoc_problem.x_is_rollout; one-wavefront-per-tile kernel): same operations as the rollout
+    that stored them, so every result must be bit-identical to the reading variant — for 1, 2 and 3 speculated trials,
+    across the Hessian switch; and a caller-supplied iterate (not a rollout) must still be READ."""
+    from aircraftoptimalcontrol_amd import problems
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 200
+    x0 = problems.random_x0(B, seed=17)
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    for ns in (1, 2, 3):
+        res = []
+        for rc in (0, 1):
+            tuned(nspec=ns, split_tiles=0, split_bw_tiles=0, fw_recompute=rc)
+            s = aoc.NewtonBatchSolver(bp, B, prm)
+            s.set_initial_from_x0(x0)
+            assert s.cur_rollout
+            res.append((s.run_fixed(11), s.current()))
+        (ha, (xa, ua)), (hb, (xb, ub)) = res
+        assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(ua, ub, equal_nan=True), ns
+        for a, b in zip(ha, hb):
+            for key in a:
+                assert np.array_equal(a[key], b[key], equal_nan=True), (ns, key)
+    # an initial iterate that is NOT the rollout of its inputs (float32-valued states shifted by one float32 ulp)
+    tuned(nspec=2, split_tiles=0, split_bw_tiles=0, fw_recompute=1)
+    s = aoc.NewtonBatchSolver(bp, B, prm)
+    s.set_initial_from_x0(x0)
+    xi, ui = s.current()
+    xi2 = xi.copy()
+    xi2[:, :, 1:] = np.nextafter(xi[:, :, 1:].astype(np.float32), np.float32(np.inf)).astype(np.float64)
+    op = orc.OracleProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    s.set_initial(xi2, ui)
+    assert not s.cur_rollout and not s.cur_is64
+    s.iterate(0)
+    sc = s.scalars()
+    xn, un = s.current()
+    for b in (0, 77, 199):
+        r = orc.newton_iterate(op, orc.params(), 0, xi2[b], ui[b], xi2[b][:, 0])
+        assert r["stepsize"] == sc["stepsize"][b] and abs(r["descent"] - sc["descent"][b]) <= 1e-8 * abs(r["descent"])
+        assert rel_err(un[b], r["uu"], 1e-3) < 1e-8
