@@ -61,8 +61,8 @@ class Tuning(C.Structure):
     """aoc_tuning (include/aoc.h): scheduling knobs; results never depend on them."""
     _fields_ = [(n, C.c_int32) for n in ("nspec", "split_tiles", "split_bw_tiles", "reserved0", "ls_wcap", "ls_kgrow",
                                          "trial_split", "solve_norepack", "ls_worklist", "ls_cpl", "ls_depth_min",
-                                         "fw_recompute")] + \
-               [("reserved", C.c_int32 * 4)]
+                                         "fw_recompute", "store_candidates")] + \
+               [("reserved", C.c_int32 * 3)]
 
 
 # every symbol include/aoc.h declares: (name, restype, argtypes)
@@ -86,13 +86,14 @@ SYMBOLS = {
     "aoc_rollout_cost": (C.c_int, [_P] * 9),
     "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
     "aoc_gradient": (C.c_int, [_P] * 7),
-    "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 8),
+    "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 9),
+    "aoc_candidate_bytes": (_Z, [_I, _I, _I]),
     "aoc_linesearch_scratch_bytes": (_Z, [_I, _I]),
     "aoc_spec_max": (_I, []),
     "aoc_default_nspec": (_I, [_I, _I]),
-    "aoc_linesearch": (C.c_int, [_P, _P, _I] + [_P] * 13),
+    "aoc_linesearch": (C.c_int, [_P, _P, _I] + [_P] * 14),
     "aoc_linesearch_search": (C.c_int, [_P, _P, _I] + [_P] * 9),
-    "aoc_linesearch_update": (C.c_int, [_P] * 12),
+    "aoc_linesearch_update": (C.c_int, [_P] * 12 + [_I, _P, _P]),
     "aoc_lqr_tracking": (C.c_int, [_P] * 9),
     "aoc_ltv_lqr": (C.c_int, [_I, _I, _I] + [_P] * 17),
     "aoc_workspace_bytes": (_Z, [_I, _I]),

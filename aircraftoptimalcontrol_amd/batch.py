@@ -310,6 +310,9 @@ class NewtonBatchSolver:
         nsp = self.n_spec
         Jt = self.ws[nel14 + nel2:nel14 + nel2 + self.spec_max * self.Bp]
         scratch = self.ws[nel14 + nel2 + self.spec_max * self.Bp:]
+        # candidate store behind the line-search scratch, as aoc_newton_iterate lays it out (small batches only)
+        sb = (lib().aoc_linesearch_scratch_bytes(self.B, self.T) + 255) // 256 * 256
+        cand = scratch[sb // 8:] if nsp > 3 and lib().aoc_candidate_bytes(self.B, self.T, nsp) <= (scratch.numel() - sb // 8) * 8 else None
         st = torch.cuda.current_stream(self.problem.device)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record(st)
@@ -317,7 +320,7 @@ class NewtonBatchSolver:
                                  _ptr(Kt), None, _ptr(self.status)), "aoc_backward")
         ev[1].record(st)
         check(lib().aoc_forward(C.byref(p), C.byref(prm), nsp, _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
-                                _ptr(Kt), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status)),
+                                _ptr(Kt), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status), _ptr(cand)),
               "aoc_forward")
         ev[2].record(st)
         check(lib().aoc_linesearch_search(C.byref(p), C.byref(prm), nsp, _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
@@ -326,7 +329,8 @@ class NewtonBatchSolver:
         ev[3].record(st)
         check(lib().aoc_linesearch_update(C.byref(p), C.byref(prm), _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
                                           _ptr(self.xb[n]), _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.stepsize),
-                                          _ptr(self.ntrials), _ptr(self.status), _ptr(scratch)), "aoc_linesearch_update")
+                                          _ptr(self.ntrials), _ptr(self.status), _ptr(scratch), nsp, _ptr(Jt), _ptr(cand)),
+              "aoc_linesearch_update")
         ev[4].record(st)
         self.cur, self.jcur, self.kk, self.cur_is64, self.cur_rollout = n, jn, kk + 1, False, True
         return ev
@@ -563,7 +567,7 @@ class GradientBatchSolver(NewtonBatchSolver):
         check(lib().aoc_linesearch(C.byref(p), C.byref(self.params), 0, _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
                                    _ptr(self.J[jc]), _ptr(self.descent), None, _ptr(self.xb[n]), _ptr(self.ub[n]),
                                    _ptr(self.J[jn]), _ptr(self.stepsize), _ptr(self.ntrials), _ptr(self.status),
-                                   _ptr(scratch)), "aoc_linesearch")
+                                   _ptr(scratch), None), "aoc_linesearch")
         self.cur, self.jcur, self.kk, self.cur_is64, self.cur_rollout = n, jn, kk + 1, False, True
 
     def direction(self):
@@ -720,7 +724,7 @@ def backward_forward(problem, xx, uu, full_hessian, stepsize_0=1.0, f32=False):
                              _ptr(lm0), _ptr(st)), "aoc_backward")
     prm = make_params(stepsize_0=stepsize_0)
     check(lib().aoc_forward(C.byref(p), C.byref(prm), 1, _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(du),
-                            _ptr(desc), _ptr(Jn), _ptr(st)), "aoc_forward")
+                            _ptr(desc), _ptr(Jn), _ptr(st), None), "aoc_forward")
     KK = unpack(Kt, B).cpu().numpy().reshape(B, 2, 7, T)
     return dict(KK=KK, du=unpack(du, B).cpu().numpy(),
                 descent=desc[:B].cpu().numpy(), lmbd0=unpack_vec(lm0, B).cpu().numpy(),

@@ -111,6 +111,7 @@ static void tuning_defaults(aoc_tuning* t) {
     t->ls_cpl = env("AOC_LS_CPL", 1);
     t->ls_depth_min = env("AOC_LS_DEPTH_MIN", 2);
     t->fw_recompute = env("AOC_FW_RECOMPUTE", 1);
+    t->store_candidates = env("AOC_STORE_CANDIDATES", 1);
 }
 
 static const aoc_tuning& tuning() {
@@ -282,14 +283,19 @@ int aoc_gradient(const aoc_problem* p, const void* x, const double* u, const dou
     return aoc64::api_gradient(p, x, u, x0, du, slope, status);
 }
 int aoc_forward(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const void* x, const double* u,
-                const double* x0, const double* Kt, double* du, double* descent, double* J_trial, int32_t* status) {
-    return aoc64::api_forward(p, prm, n_spec, x, u, x0, Kt, du, descent, J_trial, status);
+                const double* x0, const double* Kt, double* du, double* descent, double* J_trial, int32_t* status,
+                void* cand) {
+    return aoc64::api_forward(p, prm, n_spec, x, u, x0, Kt, du, descent, J_trial, status, cand);
+}
+size_t aoc_candidate_bytes(int32_t B, int32_t T, int32_t n_spec) {
+    return B >= 1 && T >= 1 && n_spec >= 1 ? aoc64::cand_bytes(B, T, n_spec) : 0;
 }
 int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const double* u, const double* x0,
                    const double* du, const double* J_cur, const double* descent, const double* J_trial, void* x_new,
-                   double* u_new, double* J_new, double* stepsize, int32_t* ntrials, int32_t* status, void* scratch) {
+                   double* u_new, double* J_new, double* stepsize, int32_t* ntrials, int32_t* status, void* scratch,
+                   const void* cand) {
     return aoc64::api_linesearch(p, prm, n_spec, u, x0, du, J_cur, descent, J_trial, x_new, u_new, J_new, stepsize,
-                                 ntrials, status, scratch);
+                                 ntrials, status, scratch, aoc64::LsFrozen{nullptr, nullptr}, cand);
 }
 int aoc_linesearch_search(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const double* u, const double* x0,
                           const double* du, const double* J_cur, const double* descent, const double* J_trial,
@@ -298,8 +304,9 @@ int aoc_linesearch_search(const aoc_problem* p, const aoc_params* prm, int32_t n
 }
 int aoc_linesearch_update(const aoc_problem* p, const aoc_params* prm, const double* u, const double* x0, const double* du,
                           void* x_new, double* u_new, double* J_new, double* stepsize, int32_t* ntrials, int32_t* status,
-                          void* scratch) {
-    return aoc64::api_ls_update(p, prm, u, x0, du, x_new, u_new, J_new, stepsize, ntrials, status, scratch);
+                          void* scratch, int32_t n_spec, const double* J_trial, const void* cand) {
+    return aoc64::api_ls_update(p, prm, u, x0, du, x_new, u_new, J_new, stepsize, ntrials, status, scratch, n_spec, J_trial,
+                                cand);
 }
 int aoc_lqr_tracking(const aoc_problem* p, const void* x_opt, const double* u_opt, const double* x_opt0,
                      const double* x0_reg, double* Kgain, void* x_reg, double* u_reg, int32_t* status) {

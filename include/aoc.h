@@ -131,7 +131,9 @@ typedef struct aoc_tuning {
     int32_t ls_cpl;         /* AOC_LS_CPL       work-list line search: candidate steps per work item / lane (1, 2 or 4; default 1) */
     int32_t ls_depth_min;   /* AOC_LS_DEPTH_MIN work-list line search: candidates tried in the first round at least (2) */
     int32_t fw_recompute;   /* AOC_FW_RECOMPUTE aoc_forward re-computes the states when aoc_problem.x_is_rollout allows it (1) */
-    int32_t reserved[4];
+    int32_t store_candidates; /* AOC_STORE_CANDIDATES aoc_newton_iterate: small batches keep the trajectories of the Armijo candidates
+                               rolled out in the forward pass, the update then copies the accepted one (1) */
+    int32_t reserved[3];
 } aoc_tuning;
 void aoc_get_tuning(aoc_tuning *out);
 void aoc_set_tuning(const aoc_tuning *t);
@@ -215,10 +217,16 @@ int aoc_gradient(const aoc_problem *prob, const void *x, const double *u, const 
  * nonlinear rollout x' from x0, cost J'_j (optcon.py:250-264).  The trials ride along with the K~
  * stream; the reference evaluates them one after the other, the verdict order is kept by
  * aoc_linesearch.
- * Outputs: du (tiled C=2), descent[ntiles*64], J_trial[n_spec][ntiles*64]. */
+ * Outputs: du (tiled C=2), descent[ntiles*64], J_trial[n_spec][ntiles*64].
+ * cand (may be NULL; used when n_spec > 3 or the batch runs its passes on several wavefronts per tile): device memory of
+ * aoc_candidate_bytes(B, T, n_spec) bytes in which every trial keeps the trajectory it rolls out (x' as float32, u',
+ * flags); handed to aoc_linesearch / aoc_linesearch_update together with n_spec and J_trial, the update of a tile whose
+ * trajectories all accepted one of these candidates is a copy, parallel over the horizon, instead of one more serial
+ * rollout — the same values either way. */
+size_t aoc_candidate_bytes(int32_t B, int32_t T, int32_t n_spec);
 int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const void *x, const double *u,
                 const double *x0, const double *Kt, double *du, double *descent, double *J_trial,
-                int32_t *status);
+                int32_t *status, void *cand);
 
 /* Armijo back-tracking (optcon.py:243-273) and the final update (optcon.py:488-491).
  * Trial ii uses alpha_ii = stepsize_0*beta^ii and is accepted iff J'(alpha_ii) <= J_cur +
@@ -231,7 +239,8 @@ int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, 
  * sequential loop, whatever the schedule (aoc_tuning).  On exhaustion the untested
  * stepsize_0*beta^armijo_maxiters is used (Q5).  Finally EVERY trajectory is rolled out with its
  * step into x_new/u_new and J_new.  stepsize[b], ntrials[b] report the result.
- * armijo_maxiters <= 63.  scratch: device memory of aoc_linesearch_scratch_bytes(B, T) bytes. */
+ * armijo_maxiters <= 63.  scratch: device memory of aoc_linesearch_scratch_bytes(B, T) bytes.  cand: NULL, or the
+ * candidate store aoc_forward filled for the same n_spec (see there). */
 size_t aoc_linesearch_scratch_bytes(int32_t B, int32_t T);
 /* Largest n_spec aoc_forward / aoc_linesearch take, and the n_spec aoc_newton_iterate uses for a batch of B
  * trajectories: 2 in general, armijo_maxiters for batches small enough to give every candidate step its own
@@ -241,7 +250,7 @@ int32_t aoc_default_nspec(int32_t B, int32_t armijo_maxiters);
 int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const double *u,
                    const double *x0, const double *du, const double *J_cur, const double *descent,
                    const double *J_trial, void *x_new, double *u_new, double *J_new, double *stepsize,
-                   int32_t *ntrials, int32_t *status, void *scratch);
+                   int32_t *ntrials, int32_t *status, void *scratch, const void *cand);
 
 /* The two halves of aoc_linesearch, which is exactly _search followed by _update on the same arguments:
  *   aoc_linesearch_search = armijo_stepsize for every trajectory (optcon.py:204-327): stepsize[b], ntrials[b]; the
@@ -255,7 +264,8 @@ int aoc_linesearch_search(const aoc_problem *prob, const aoc_params *prm, int32_
                           const double *J_trial, double *stepsize, int32_t *ntrials, void *scratch);
 int aoc_linesearch_update(const aoc_problem *prob, const aoc_params *prm, const double *u, const double *x0,
                           const double *du, void *x_new, double *u_new, double *J_new, double *stepsize,
-                          int32_t *ntrials, int32_t *status, void *scratch);
+                          int32_t *ntrials, int32_t *status, void *scratch, int32_t n_spec, const double *J_trial,
+                          const void *cand);
 
 /* lqr_tracking.lqr_tracking (lqr_tracking.py:245-283): linearise about (x_opt,u_opt), non-augmented
  * Riccati/gain recursion with the constant weights QQt,RRt,QQT of `prob` and S = 0

@@ -676,3 +676,34 @@ def test_forward_state_recomputation_does_not_change_results(aoc, tuned):
         r = orc.newton_iterate(op, orc.params(), 0, xi2[b], ui[b], xi2[b][:, 0])
         assert r["stepsize"] == sc["stepsize"][b] and abs(r["descent"] - sc["descent"][b]) <= 1e-8 * abs(r["descent"])
         assert rel_err(un[b], r["uu"], 1e-3) < 1e-8
+
+
+def test_stored_candidates_do_not_change_results(aoc, tuned):
+    """Small batches: every Armijo candidate rides along in the forward pass, the trial wavefronts keep the trajectories
+    they roll out, and the update of a tile whose trajectories all accepted one of them is a copy instead of a rollout
+    (aoc_tuning.store_candidates).  Against the rollout update: bit-identical iterates, costs and flags over 22
+    fixed iterations — the late ones exhaust line searches, whose tiles must fall back to the rollout — with all 10
+    candidates speculated and with 7 (searches that continue beyond the stored candidates)."""
+    from aircraftoptimalcontrol_amd import problems, _lib
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 330
+    x0 = problems.perturbed_x0(pr, B, seed=14)
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    for ns in (10, 7):
+        res = []
+        for keep in (0, 1):
+            tuned(nspec=ns, store_candidates=keep)
+            s = aoc.NewtonBatchSolver(bp, B, prm)
+            s.set_initial_from_x0(x0)
+            hist = []
+            for kk in range(22):
+                s.iterate_timed(kk) if kk % 3 == 2 else s.iterate(kk)
+                hist.append(s.scalars())
+            res.append((hist, s.current()))
+        (ha, (xa, ua)), (hb, (xb, ub)) = res
+        assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(ua, ub, equal_nan=True), ns
+        for a, b in zip(ha, hb):
+            for key in a:
+                assert np.array_equal(a[key], b[key], equal_nan=True), (ns, key)
+        assert any((h["status"] & _lib.ST_ARMIJO_EXH).any() for h in ha), "the run should contain exhausted searches"
