@@ -312,7 +312,9 @@ class NewtonBatchSolver:
         scratch = self.ws[nel14 + nel2 + self.spec_max * self.Bp:]
         # candidate store behind the line-search scratch, as aoc_newton_iterate lays it out (small batches only)
         sb = (lib().aoc_linesearch_scratch_bytes(self.B, self.T) + 255) // 256 * 256
-        cand = scratch[sb // 8:] if nsp > 3 and lib().aoc_candidate_bytes(self.B, self.T, nsp) <= (scratch.numel() - sb // 8) * 8 else None
+        tn = _lib.Tuning()
+        lib().aoc_get_tuning(C.byref(tn))
+        cand = scratch[sb // 8:] if nsp > 3 and tn.store_candidates else None
         st = torch.cuda.current_stream(self.problem.device)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record(st)

@@ -373,9 +373,17 @@ __host__ __device__ constexpr int sidx(int i, int j) { return i * 6 - (i * (i - 
 // ---------------------------------------------------------------------------------------------
 struct StageFlags { bool singular, regularised; };
 
-__device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, real P[21], real p[6],
-                                                const real Qs[21], real s02, real s03, real s05,
-                                                const real hq[6], const real hr[2], real Kt[14]) {
+// Columns COLS (bit j: column j of P_t and of the feedback gains K) of one stage, and with AFFINE the affine terms
+// (sigma = Kt[0], Kt[7], and p_t in place).  P is read only; Pn receives the entries (i,j), i <= j, of the columns in
+// COLS.  lqr_stage = all six columns + affine terms.  The four-wavefront backward pass of small batches
+// (k_backward4) gives three wavefronts the columns {0,1,2}, {3,4} and {5} + affine: every entry is computed by the
+// expressions below whichever wavefront owns it, so the split changes no rounding.  A column j needs the rows
+// G[:,i] = (B^T P A + S)[:,i] of all i <= j (three entries of column i of P A each), the affine terms need all six.
+template <int COLS, bool AFFINE>
+__device__ __forceinline__ StageFlags lqr_stage_part(const KConst& k, const Lin& l, const real P[21], real p[6],
+                                                     const real Qs[21], real s02, real s03, real s05,
+                                                     const real hq[6], const real hr[2], real Kt[14], real Pn[21]) {
+    constexpr int JMAX = AFFINE ? 5 : (COLS >= 32 ? 5 : COLS >= 16 ? 4 : COLS >= 8 ? 3 : COLS >= 4 ? 2 : COLS >= 2 ? 1 : 0);
     // M = R + B^T P B  (2x2, symmetric), from the six entries of P that B touches
     const real P22 = P[sidx(2, 2)], P24 = P[sidx(2, 4)], P25 = P[sidx(2, 5)], P44 = P[sidx(4, 4)],
                  P45 = P[sidx(4, 5)], P55 = P[sidx(5, 5)];
@@ -394,19 +402,25 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, r
     const bool pd = (M00 + M11 > R(0.0)) && (det > R(0.0));
     fl.regularised = !pd;
     // affine column: h = B^T p + r/2, M^-1 h
-    const real h0 = l.b20 * p[2] + l.b50 * p[5] + hr[0];
-    const real h1 = k.b41 * p[4] + hr[1];
-    const real mh0 = i00 * h0 + i01 * h1, mh1 = i01 * h0 + i11 * h1;
-    Kt[0] = -mh0; Kt[7] = -mh1;
+    real h0 = R(0.0), h1 = R(0.0), mh0 = R(0.0), mh1 = R(0.0);
+    if (AFFINE) {
+        h0 = l.b20 * p[2] + l.b50 * p[5] + hr[0];
+        h1 = k.b41 * p[4] + hr[1];
+        mh0 = i00 * h0 + i01 * h1; mh1 = i01 * h0 + i11 * h1;
+        Kt[0] = -mh0; Kt[7] = -mh1;
+    }
     // Column by column: W[:,j] = (P A)[:,j], G[:,j] = (B^T W)[:,j] + S[:,j], M^-1 G[:,j],
     // z = (A^T W)[:,j], P_t[i,j] = Q[i,j] + z[i] - G[:,i]^T M^-1 G[:,j] for i <= j.  Only one column of W
     // is alive at a time; the new P is built beside the old one.
-    real Pn[21], G0[6], G1[6];
+    real G0[6], G1[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
+        const bool own = (COLS >> j) & 1;
+        if (!own && j > JMAX) continue;
         real w[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
+            if (!own && i != 2 && i != 4 && i != 5) continue;   // G needs rows 2, 4, 5 of the column only
             const real pi0 = SYM(P, i, 0), pi1 = SYM(P, i, 1), pi2 = SYM(P, i, 2), pi3 = SYM(P, i, 3),
                          pi4 = SYM(P, i, 4), pi5 = SYM(P, i, 5);
             w[i] = j == 0 ? pi0
@@ -422,6 +436,7 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, r
         if (j == 3) g0 += s03;
         if (j == 5) g0 += s05;
         G0[j] = g0; G1[j] = g1;
+        if (!own) continue;
         const real mg0 = i00 * g0 + i01 * g1, mg1 = i01 * g0 + i11 * g1;
         Kt[1 + j] = -mg0; Kt[8 + j] = -mg1;
         const real z[6] = {w[0], w[1],
@@ -438,18 +453,28 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, r
         if (rdet == R(0.0)) fl.singular = true;
         const real ird = rcp_fast(rdet);
         const real j00 = r11 * ird, j01 = -M01 * ird, j11 = r00 * ird;
-        Kt[0] = -(j00 * h0 + j01 * h1); Kt[7] = -(j01 * h0 + j11 * h1);
+        if (AFFINE) { Kt[0] = -(j00 * h0 + j01 * h1); Kt[7] = -(j01 * h0 + j11 * h1); }
 #pragma unroll
         for (int j = 0; j < 6; j++) {
+            if (!((COLS >> j) & 1)) continue;
             Kt[1 + j] = -(j00 * G0[j] + j01 * G1[j]);
             Kt[8 + j] = -(j01 * G0[j] + j11 * G1[j]);
         }
     }
-    // p_t = q/2 + A^T p - G^T (M^-1 h)
-    real ap[6];
-    At_vec(k, l, p, ap);
+    if (AFFINE) {  // p_t = q/2 + A^T p - G^T (M^-1 h)
+        real ap[6];
+        At_vec(k, l, p, ap);
 #pragma unroll
-    for (int i = 0; i < 6; i++) p[i] = hq[i] + ap[i] - (G0[i] * mh0 + G1[i] * mh1);
+        for (int i = 0; i < 6; i++) p[i] = hq[i] + ap[i] - (G0[i] * mh0 + G1[i] * mh1);
+    }
+    return fl;
+}
+
+__device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, real P[21], real p[6],
+                                                const real Qs[21], real s02, real s03, real s05,
+                                                const real hq[6], const real hr[2], real Kt[14]) {
+    real Pn[21];
+    const StageFlags fl = lqr_stage_part<63, true>(k, l, P, p, Qs, s02, s03, s05, hq, hr, Kt, Pn);
 #pragma unroll
     for (int e = 0; e < 21; e++) P[e] = Pn[e];
     return fl;

@@ -78,7 +78,8 @@ def kernel_names(ntiles, full):
     wl = t.ls_worklist > 0 or (t.ls_worklist < 0 and ntiles > t.split_tiles)
     small = ntiles <= t.split_tiles
     return {
-        "backward": ("k_backward2<%s, float>" if ntiles <= t.split_bw_tiles else "k_backward<%s, float>") % fl,
+        "backward": ("k_backward4<%s, float>" if ntiles <= min(t.bw4_tiles, t.split_bw_tiles) else
+                     "k_backward2<%s, float>" if ntiles <= t.split_bw_tiles else "k_backward<%s, float>") % fl,
         "forward": "k_forward_split<true, false, float>" if small else "k_forward<true, false, 2, float>",
         "linesearch_update": "k_ls_final_split<true, false, float>" if small else "k_ls_final<true, false, float>",
         "linesearch_search": ("phase: k_ls_init_wl, k_ls_plan_wl, k_ls_trial_wl<true, false, %d> x2, k_ls_replan" % max(t.ls_cpl, 1)) if wl

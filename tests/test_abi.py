@@ -34,7 +34,7 @@ def test_geometry_helpers_and_errors():
     up = lambda v: (v + 255) // 256 * 256
     assert lib.aoc_workspace_bytes(64, 500) == (64 * 500 * 16 * 8 + lib.aoc_spec_max() * 64 * 8 + up(lib.aoc_linesearch_scratch_bytes(64, 500))
                                                 + lib.aoc_candidate_bytes(64, 500, lib.aoc_spec_max()))
-    assert lib.aoc_candidate_bytes(64, 500, 10) == 10 * (64 * 500 * (6 * 4 + 2 * 8) + 64 * 4)
+    assert lib.aoc_candidate_bytes(64, 500, 10) == 10 * (64 * 500 * 48 + 64 * 4)
     big = 131072   # large batches: two candidates in the one-wavefront forward pass, nothing stored
     assert lib.aoc_workspace_bytes(big, 500) == big * 500 * 16 * 8 + lib.aoc_spec_max() * big * 8 + up(lib.aoc_linesearch_scratch_bytes(big, 500))
     assert b"gfx950" in lib.aoc_version()

@@ -707,3 +707,39 @@ def test_stored_candidates_do_not_change_results(aoc, tuned):
             for key in a:
                 assert np.array_equal(a[key], b[key], equal_nan=True), (ns, key)
         assert any((h["status"] & _lib.ST_ARMIJO_EXH).any() for h in ha), "the run should contain exhausted searches"
+
+
+def test_four_wavefront_backward_equals_the_others(aoc, tuned):
+    """Tiny batches run the Riccati / gain half of the backward pass on three wavefronts (columns {0,1,2}, {3,4},
+    {5} + affine terms; k_backward4).  Against the two-wavefront and the one-wavefront kernel: gains, direction,
+    descent, costate and every iterate over 12 iterations (Gauss-Newton and full Hessian) bit for bit, incl. a golden
+    case with regularised stages."""
+    from aircraftoptimalcontrol_amd import problems
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 150
+    x0 = problems.random_x0(B, seed=23)
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    variants = (dict(bw4_tiles=256), dict(bw4_tiles=0), dict(bw4_tiles=0, split_bw_tiles=0))
+    res = []
+    for kn in variants:
+        tuned(**kn)
+        s = aoc.NewtonBatchSolver(bp, B, prm)
+        s.set_initial_from_x0(x0)
+        res.append((s.run_fixed(12), s.current()))
+    ha, (xa, ua) = res[0]
+    assert max(int(h["status"].max()) for h in ha) & 8, "some stage should have been regularised after the Hessian switch"
+    for hb, (xb, ub) in res[1:]:
+        assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(ua, ub, equal_nan=True)
+        for a, b in zip(ha, hb):
+            for key in a:
+                assert np.array_equal(a[key], b[key], equal_nan=True), key
+    g = load_golden("g3_lqr_b_full_init_T1000")          # 18 regularised stages
+    _, bp2, _ = _problem(aoc, "problem_step_T1000")
+    outs = []
+    for kn in variants:
+        tuned(**kn)
+        outs.append(aoc.backward_forward(bp2, g["xx"][None], g["uu"][None], 1))
+    for o in outs[1:]:
+        for key in ("KK", "du", "descent", "lmbd0", "J_trial0", "status"):
+            assert np.array_equal(outs[0][key], o[key]), key
