@@ -80,7 +80,9 @@ def kernel_names(ntiles, full):
     return {
         "backward": ("k_backward4<%s, float>" if ntiles <= min(t.bw4_tiles, t.split_bw_tiles) else
                      "k_backward2<%s, float>" if ntiles <= t.split_bw_tiles else "k_backward<%s, float>") % fl,
-        "forward": "k_forward_split<true, false, float>" if small else "k_forward<true, false, 2, float>",
+        # <diagonal, shared reference, 2 speculated trials, states re-computed (the iterates of the run are rollouts), float32 states>
+        "forward": "k_forward_split<true, false, float>" if small else
+                   "k_forward<true, false, 2, %s, float>" % ("true" if t.fw_recompute else "false"),
         "linesearch_update": "k_ls_final_split<true, false, float>" if small else "k_ls_final<true, false, float>",
         "linesearch_search": ("phase: k_ls_init_wl, k_ls_plan_wl, k_ls_trial_wl<true, false, %d> x2, k_ls_replan" % max(t.ls_cpl, 1)) if wl
         else "phase: k_ls_init, k_ls_plan, k_ls_trial*, k_ls_resolve (round-based search)",
