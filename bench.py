@@ -233,6 +233,8 @@ def run(a):
         e = {"pass": pname, "kernel": names[pname], "iterations": which, "launches": int(pick.sum()), "avg_ms": avg}
         if pname in BYTES:
             alg, sto = BYTES[pname]
+            if pname == "forward" and ", 2, true, float>" in names[pname]:
+                sto -= 24          # the nominal states are re-computed, not read (float32: 6 x 4 B)
             e.update(algorithmic_bytes=alg * units, stored_bytes=sto * units,
                      algorithmic_GBps=alg * units / avg / 1e6, stored_GBps=sto * units / avg / 1e6,
                      frac_algorithmic=alg * units / avg / 1e6 / HBM_PEAK_GBS, frac_stored=sto * units / avg / 1e6 / HBM_PEAK_GBS,

@@ -134,7 +134,8 @@ typedef struct aoc_tuning {
     int32_t store_candidates; /* AOC_STORE_CANDIDATES aoc_newton_iterate: small batches keep the trajectories of the Armijo candidates
                                rolled out in the forward pass, the update then copies the accepted one (1) */
     int32_t bw4_tiles;      /* AOC_BW4_TILES    backward pass on four wavefronts per tile (Riccati columns over three) up to this many tiles (256) */
-    int32_t reserved[2];
+    int32_t bw4_tiles_producers2; /* AOC_BW5       ... with two producer wavefronts in Gauss-Newton iterations (1) */
+    int32_t reserved[1];
 } aoc_tuning;
 void aoc_get_tuning(aoc_tuning *out);
 void aoc_set_tuning(const aoc_tuning *t);

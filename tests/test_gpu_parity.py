@@ -711,7 +711,8 @@ def test_stored_candidates_do_not_change_results(aoc, tuned):
 
 def test_four_wavefront_backward_equals_the_others(aoc, tuned):
     """Tiny batches run the Riccati / gain half of the backward pass on three wavefronts (columns {0,1,2}, {3,4},
-    {5} + affine terms; k_backward4).  Against the two-wavefront and the one-wavefront kernel: gains, direction,
+    {5} + affine terms; k_backward4) and, without costate, the producer half on two (k_backward5).  Against the
+    two-wavefront and the one-wavefront kernel: gains, direction,
     descent, costate and every iterate over 12 iterations (Gauss-Newton and full Hessian) bit for bit, incl. a golden
     case with regularised stages."""
     from aircraftoptimalcontrol_amd import problems
@@ -720,7 +721,10 @@ def test_four_wavefront_backward_equals_the_others(aoc, tuned):
     B = 150
     x0 = problems.random_x0(B, seed=23)
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
-    variants = (dict(bw4_tiles=256), dict(bw4_tiles=0), dict(bw4_tiles=0, split_bw_tiles=0))
+    # default: k_backward5 (two producers) in Gauss-Newton iterations, k_backward4 with the costate; then k_backward4
+    # everywhere, k_backward2, k_backward
+    variants = (dict(bw4_tiles=256), dict(bw4_tiles=256, bw4_tiles_producers2=0), dict(bw4_tiles=0),
+                dict(bw4_tiles=0, split_bw_tiles=0))
     res = []
     for kn in variants:
         tuned(**kn)
