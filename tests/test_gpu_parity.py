@@ -709,22 +709,18 @@ def test_stored_candidates_do_not_change_results(aoc, tuned):
         assert any((h["status"] & _lib.ST_ARMIJO_EXH).any() for h in ha), "the run should contain exhausted searches"
 
 
-def test_four_wavefront_backward_equals_the_others(aoc, tuned):
-    """Tiny batches run the Riccati / gain half of the backward pass on three wavefronts (columns {0,1,2}, {3,4},
-    {5} + affine terms; k_backward4) and, without costate, the producer half on two (k_backward5).  Against the
-    two-wavefront and the one-wavefront kernel: gains, direction,
-    descent, costate and every iterate over 12 iterations (Gauss-Newton and full Hessian) bit for bit, incl. a golden
-    case with regularised stages."""
+def test_five_wavefront_backward_equals_the_others(aoc, tuned):
+    """Tiny batches run the Gauss-Newton backward pass on five wavefronts per tile (k_backward5: two producers taking
+    the stages in turn, the Riccati columns {0,1,2}, {3,4}, {5} + affine terms on three consumers).  Against the
+    two-wavefront and the one-wavefront kernel: gains, direction, descent and every iterate over 12 iterations bit for
+    bit (the full-Hessian iterations run k_backward2 in every variant), incl. a golden Gauss-Newton case."""
     from aircraftoptimalcontrol_amd import problems
     pr = problems.step_maneuver(1.0, 2e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     B = 150
     x0 = problems.random_x0(B, seed=23)
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
-    # default: k_backward5 (two producers) in Gauss-Newton iterations, k_backward4 with the costate; then k_backward4
-    # everywhere, k_backward2, k_backward
-    variants = (dict(bw4_tiles=256), dict(bw4_tiles=256, bw4_tiles_producers2=0), dict(bw4_tiles=0),
-                dict(bw4_tiles=0, split_bw_tiles=0))
+    variants = (dict(bw5_tiles=256), dict(bw5_tiles=0), dict(bw5_tiles=0, split_bw_tiles=0))
     res = []
     for kn in variants:
         tuned(**kn)
@@ -738,12 +734,20 @@ def test_four_wavefront_backward_equals_the_others(aoc, tuned):
         for a, b in zip(ha, hb):
             for key in a:
                 assert np.array_equal(a[key], b[key], equal_nan=True), key
-    g = load_golden("g3_lqr_b_full_init_T1000")          # 18 regularised stages
     _, bp2, _ = _problem(aoc, "problem_step_T1000")
-    outs = []
-    for kn in variants:
-        tuned(**kn)
-        outs.append(aoc.backward_forward(bp2, g["xx"][None], g["uu"][None], 1))
-    for o in outs[1:]:
-        for key in ("KK", "du", "descent", "lmbd0", "J_trial0", "status"):
-            assert np.array_equal(outs[0][key], o[key]), key
+    for case, fh in (("g3_lqr_a_gn_init_T1000", 0), ("g3_lqr_b_full_init_T1000", 1)):   # b: 18 regularised stages
+        g = load_golden(case)
+        outs = []
+        for kn in variants:
+            tuned(**kn)
+            s_ = aoc.NewtonBatchSolver(bp2, 1, prm)      # Gauss-Newton through aoc_newton_iterate: no costate asked for
+            xi = g["xx"][None].copy()
+            s_.set_initial(xi, g["uu"][None])
+            s_.iterate(9 if fh else 0)
+            outs.append((s_.scalars(), s_.current(), aoc.backward_forward(bp2, g["xx"][None], g["uu"][None], fh)))
+        for sc, (xx, uu), o in outs[1:]:
+            for key in sc:
+                assert np.array_equal(outs[0][0][key], sc[key]), (case, key)
+            assert np.array_equal(outs[0][1][0], xx) and np.array_equal(outs[0][1][1], uu), case
+            for key in ("KK", "du", "descent", "lmbd0", "J_trial0", "status"):
+                assert np.array_equal(outs[0][2][key], o[key]), (case, key)
