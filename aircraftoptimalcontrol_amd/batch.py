@@ -314,7 +314,8 @@ class NewtonBatchSolver:
         sb = (lib().aoc_linesearch_scratch_bytes(self.B, self.T) + 255) // 256 * 256
         tn = _lib.Tuning()
         lib().aoc_get_tuning(C.byref(tn))
-        cand = scratch[sb // 8:] if nsp > 3 and tn.store_candidates else None
+        stored = nsp > 3 and nsp >= prm.armijo_maxiters and self.nt * ((nsp + 2) // 3) <= 256   # as aoc_newton_iterate decides
+        cand = scratch[sb // 8:] if stored and tn.store_candidates else None
         st = torch.cuda.current_stream(self.problem.device)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record(st)

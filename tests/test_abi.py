@@ -32,11 +32,11 @@ def test_geometry_helpers_and_errors():
     assert lib.aoc_ntiles(1) == 1 and lib.aoc_ntiles(64) == 1 and lib.aoc_ntiles(65) == 2
     assert lib.aoc_tiled_elems(100, 500, 6) == 2 * 500 * 6 * 64
     up = lambda v: (v + 255) // 256 * 256
-    assert lib.aoc_workspace_bytes(64, 500) == (64 * 500 * 16 * 8 + lib.aoc_spec_max() * 64 * 8 + up(lib.aoc_linesearch_scratch_bytes(64, 500))
-                                                + lib.aoc_candidate_bytes(64, 500, lib.aoc_spec_max()))
+    base = lambda B: B * 500 * 16 * 8 + lib.aoc_spec_max() * B * 8 + up(lib.aoc_linesearch_scratch_bytes(B, 500))
+    # small batches with at most one forward workgroup per CU keep the candidate trajectories (all aoc_spec_max() of them)
+    assert lib.aoc_workspace_bytes(64, 500) == base(64) + lib.aoc_candidate_bytes(64, 500, lib.aoc_spec_max())
     assert lib.aoc_candidate_bytes(64, 500, 10) == 10 * (64 * 500 * 48 + 64 * 4)
-    big = 131072   # large batches: two candidates in the one-wavefront forward pass, nothing stored
-    assert lib.aoc_workspace_bytes(big, 500) == big * 500 * 16 * 8 + lib.aoc_spec_max() * big * 8 + up(lib.aoc_linesearch_scratch_bytes(big, 500))
+    assert lib.aoc_workspace_bytes(8192, 500) == base(8192) and lib.aoc_workspace_bytes(131072, 500) == base(131072)
     assert b"gfx950" in lib.aoc_version()
     assert lib.aoc_strerror(-1) == b"invalid argument"
     # struct layout must match the header: 9 doubles + 76 doubles + 8 int32 + 2 pointers

@@ -682,15 +682,14 @@ def test_stored_candidates_do_not_change_results(aoc, tuned):
     """Small batches: every Armijo candidate rides along in the forward pass, the trial wavefronts keep the trajectories
     they roll out, and the update of a tile whose trajectories all accepted one of them is a copy instead of a rollout
     (aoc_tuning.store_candidates).  Against the rollout update: bit-identical iterates, costs and flags over 22
-    fixed iterations — the late ones exhaust line searches, whose tiles must fall back to the rollout — with all 10
-    candidates speculated and with 7 (searches that continue beyond the stored candidates)."""
+    fixed iterations — the late ones exhaust line searches, whose tiles must fall back to the rollout."""
     from aircraftoptimalcontrol_amd import problems, _lib
     pr = problems.step_maneuver(1.0, 2e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     B = 330
     x0 = problems.perturbed_x0(pr, B, seed=14)
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
-    for ns in (10, 7):
+    for ns in (10,):
         res = []
         for keep in (0, 1):
             tuned(nspec=ns, store_candidates=keep)
