@@ -33,10 +33,14 @@ def test_geometry_helpers_and_errors():
     assert lib.aoc_tiled_elems(100, 500, 6) == 2 * 500 * 6 * 64
     up = lambda v: (v + 255) // 256 * 256
     base = lambda B: B * 500 * 16 * 8 + lib.aoc_spec_max() * B * 8 + up(lib.aoc_linesearch_scratch_bytes(B, 500))
-    # small batches with at most one forward workgroup per CU keep the candidate trajectories (all aoc_spec_max() of them)
+    # small batches with at most one forward workgroup per CU keep the candidate trajectories; the region is sized for the
+    # largest need of any batch up to B, because aoc_newton_solve runs its smaller generations in the same workspace
     assert lib.aoc_workspace_bytes(64, 500) == base(64) + lib.aoc_candidate_bytes(64, 500, lib.aoc_spec_max())
     assert lib.aoc_candidate_bytes(64, 500, 10) == 10 * (64 * 500 * 48 + 64 * 4)
-    assert lib.aoc_workspace_bytes(8192, 500) == base(8192) and lib.aoc_workspace_bytes(131072, 500) == base(131072)
+    sizes = [lib.aoc_workspace_bytes(B, 500) for B in (1, 64, 65, 1000, 4096, 6000, 8192, 8193, 40000, 131072)]
+    assert sizes == sorted(sizes)
+    assert lib.aoc_workspace_bytes(131072, 500) - base(131072) == max(lib.aoc_workspace_bytes(64 * t, 500) - base(64 * t) for t in range(1, 257))
+    assert lib.aoc_workspace_bytes(131072, 500) - base(131072) < 1.3e9
     assert b"gfx950" in lib.aoc_version()
     assert lib.aoc_strerror(-1) == b"invalid argument"
     # struct layout must match the header: 9 doubles + 76 doubles + 8 int32 + 2 pointers

@@ -500,13 +500,16 @@ def _same_solve(a, b):
         assert np.array_equal(a["history"][key], b["history"][key], equal_nan=(key != "ntrials")), key
 
 
+@pytest.mark.parametrize("worklist", [0, 1])
 @pytest.mark.parametrize("sync_every", [0, 3])
-def test_device_solve_equals_host_loop(aoc, sync_every):
+def test_device_solve_equals_host_loop(aoc, sync_every, worklist, tuned):
     """aoc_newton_solve (loop, stopping rule Q6, return index Q7, Q8 on the device) against solve(compact=False),
     the host loop over aoc_newton_iterate: returned iterates, iteration counts, status flags and histories
     bit for bit.  max_iters is chosen so that part of the batch stops by the descent test and the rest runs out
     of iterations; sync_every = 0 never looks at the device between iterations."""
     from aircraftoptimalcontrol_amd import problems
+    if worklist:   # the large-batch arrangement: one-wavefront kernels, two speculated trials, work-list search (frozen lanes!)
+        tuned(ls_worklist=1, nspec=2, split_tiles=0, split_bw_tiles=0)
     pr = problems.step_maneuver(1.0, 2e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     B = 700
