@@ -97,15 +97,15 @@ SYMBOLS = {
     "aoc_lqr_tracking": (C.c_int, [_P] * 9),
     "aoc_ltv_lqr": (C.c_int, [_I, _I, _I] + [_P] * 17),
     "aoc_workspace_bytes": (_Z, [_I, _I]),
-    "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 12),
+    "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 5 + [_Z] + [_P] * 7),
     "aoc_solve_workspace_bytes": (_Z, [_I, _I]),
-    "aoc_newton_solve": (C.c_int, [_P] * 6 + [_I] + [_P] * 10),
-    "aoc_mpc_step": (C.c_int, [_P] * 3 + [_I] + [_P] * 20),
+    "aoc_newton_solve": (C.c_int, [_P] * 6 + [_Z, _I] + [_P] * 10),
+    "aoc_mpc_step": (C.c_int, [_P] * 3 + [_I] + [_P] * 6 + [_Z] + [_P] * 14),
     "aoc_traj_cost_f32": (C.c_int, [_P] * 5),
     "aoc_initial_trajectory_f32": (C.c_int, [_P, _D, _D, _P, _P, _P]),
     "aoc_rollout_cost_f32": (C.c_int, [_P] * 9),
     "aoc_workspace_bytes_f32": (_Z, [_I, _I]),
-    "aoc_newton_iterate_f32": (C.c_int, [_P, _P, _I] + [_P] * 12),
+    "aoc_newton_iterate_f32": (C.c_int, [_P, _P, _I] + [_P] * 5 + [_Z] + [_P] * 7),
 }
 
 _lib = None

@@ -284,7 +284,7 @@ class NewtonBatchSolver:
         c, n = self.cur, (self.cur + 1) % 3
         jc, jn = self.jcur, 1 - self.jcur
         check(lib().aoc_newton_iterate(C.byref(p), C.byref(self.params), int(kk), _ptr(x), _ptr(self.ub[c]),
-                                       _ptr(self.x0), _ptr(self.J[jc]), _ptr(self.ws), _ptr(self.xb[n]),
+                                       _ptr(self.x0), _ptr(self.J[jc]), _ptr(self.ws), self.ws.numel() * 8, _ptr(self.xb[n]),
                                        _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.descent), _ptr(self.stepsize),
                                        _ptr(self.ntrials), _ptr(self.status)), "aoc_newton_iterate")
         self.cur, self.jcur, self.kk, self.cur_is64, self.cur_rollout = n, jn, kk + 1, False, True
@@ -521,7 +521,7 @@ class NewtonBatchSolver:
         n_run = C.c_int32(0)
         torch.cuda.synchronize(dev)
         t_start = time.perf_counter()
-        check(lib().aoc_newton_solve(C.byref(p), C.byref(prm), _ptr(x), _ptr(self.ub[self.cur]), _ptr(self.x0), _ptr(ws),
+        check(lib().aoc_newton_solve(C.byref(p), C.byref(prm), _ptr(x), _ptr(self.ub[self.cur]), _ptr(self.x0), _ptr(ws), ws.numel() * 8,
                                      int(sync_every), _ptr(x_star), _ptr(u_star), _ptr(iters), _ptr(ret), _ptr(status),
                                      _ptr(hc), _ptr(hd), _ptr(hs), _ptr(hn), C.byref(n_run)), "aoc_newton_solve")
         torch.cuda.synchronize(dev)
@@ -842,7 +842,7 @@ class NewtonBatchSolverF32:
         c, n = self.cur, 1 - self.cur
         jc, jn = self.jcur, 1 - self.jcur
         check(lib().aoc_newton_iterate_f32(C.byref(p), C.byref(self.params), int(kk), _ptr(self.xb[c]), _ptr(self.ub[c]),
-                                           _ptr(self.x0), _ptr(self.J[jc]), _ptr(self.ws), _ptr(self.xb[n]),
+                                           _ptr(self.x0), _ptr(self.J[jc]), _ptr(self.ws), self.ws.numel() * 4, _ptr(self.xb[n]),
                                            _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.descent), _ptr(self.stepsize),
                                            _ptr(self.ntrials), _ptr(self.status)), "aoc_newton_iterate_f32")
         self.cur, self.jcur, self.kk = n, jn, kk + 1

@@ -321,27 +321,27 @@ int aoc_ltv_lqr(int32_t nb, int32_t T, int32_t augmented, const double* A, const
 }
 size_t aoc_workspace_bytes(int32_t B, int32_t T) { return aoc64::api_workspace_bytes(B, T); }
 int aoc_newton_iterate(const aoc_problem* p, const aoc_params* prm, int32_t kk, const void* x, const double* u,
-                       const double* x0, const double* J_cur, void* workspace, void* x_new, double* u_new,
-                       double* J_new, double* descent, double* stepsize, int32_t* ntrials, int32_t* status) {
-    return aoc64::api_newton_iterate(p, prm, kk, x, u, x0, J_cur, workspace, x_new, u_new, J_new, descent, stepsize,
-                                     ntrials, status);
+                       const double* x0, const double* J_cur, void* workspace, size_t workspace_bytes, void* x_new,
+                       double* u_new, double* J_new, double* descent, double* stepsize, int32_t* ntrials, int32_t* status) {
+    return aoc64::api_newton_iterate(p, prm, kk, x, u, x0, J_cur, workspace, workspace_bytes, x_new, u_new, J_new, descent,
+                                     stepsize, ntrials, status);
 }
 
 size_t aoc_solve_workspace_bytes(int32_t B, int32_t T) { return aoc64::api_solve_workspace_bytes(B, T); }
 int aoc_newton_solve(const aoc_problem* p, const aoc_params* prm, const void* x_init, const double* u_init,
-                     const double* x0, void* workspace, int32_t sync_every, void* x_star, double* u_star,
-                     int32_t* iters, int32_t* ret_index, int32_t* status, double* hist_cost, double* hist_descent,
-                     double* hist_stepsize, int32_t* hist_ntrials, int32_t* n_run) {
-    return aoc64::api_newton_solve(p, prm, x_init, u_init, x0, workspace, sync_every, x_star, u_star, iters, ret_index,
+                     const double* x0, void* workspace, size_t workspace_bytes, int32_t sync_every, void* x_star,
+                     double* u_star, int32_t* iters, int32_t* ret_index, int32_t* status, double* hist_cost,
+                     double* hist_descent, double* hist_stepsize, int32_t* hist_ntrials, int32_t* n_run) {
+    return aoc64::api_newton_solve(p, prm, x_init, u_init, x0, workspace, workspace_bytes, sync_every, x_star, u_star, iters, ret_index,
                                    status, hist_cost, hist_descent, hist_stepsize, hist_ntrials, n_run);
 }
 
 int aoc_mpc_step(const aoc_problem* p_track, const aoc_problem* p_next, const aoc_params* prm, int32_t n_newton,
                  const void* x_cur, const double* u_cur, double* x0, double* x_true, const double* disturbance,
-                 void* workspace, double* Kgain, void* x_a, double* u_a, void* x_b, double* u_b, double* J_a, double* J_b,
-                 double* descent, double* stepsize, int32_t* ntrials, int32_t* status, double* K0, double* u_applied,
-                 int32_t* final_slot) {
-    return aoc64::api_mpc_step(p_track, p_next, prm, n_newton, x_cur, u_cur, x0, x_true, disturbance, workspace, Kgain, x_a,
+                 void* workspace, size_t workspace_bytes, double* Kgain, void* x_a, double* u_a, void* x_b, double* u_b,
+                 double* J_a, double* J_b, double* descent, double* stepsize, int32_t* ntrials, int32_t* status, double* K0,
+                 double* u_applied, int32_t* final_slot) {
+    return aoc64::api_mpc_step(p_track, p_next, prm, n_newton, x_cur, u_cur, x0, x_true, disturbance, workspace, workspace_bytes, Kgain, x_a,
                                u_a, x_b, u_b, J_a, J_b, descent, stepsize, ntrials, status, K0, u_applied, final_slot);
 }
 
@@ -361,11 +361,11 @@ int aoc_rollout_cost_f32(const aoc_problem* p, const float* x0, const float* u, 
 }
 size_t aoc_workspace_bytes_f32(int32_t B, int32_t T) { return aoc32::api_workspace_bytes(B, T); }
 int aoc_newton_iterate_f32(const aoc_problem* p, const aoc_params* prm, int32_t kk, const float* x, const float* u,
-                           const float* x0, const float* J_cur, void* workspace, float* x_new, float* u_new,
-                           float* J_new, float* descent, float* stepsize, int32_t* ntrials, int32_t* status) {
+                           const float* x0, const float* J_cur, void* workspace, size_t workspace_bytes, float* x_new,
+                           float* u_new, float* J_new, float* descent, float* stepsize, int32_t* ntrials, int32_t* status) {
     if (p && p->ref_per_traj) return einval("aoc_newton_iterate_f32: per-trajectory reference curves exist in the fp64 build only");
-    return aoc32::api_newton_iterate(p, prm, kk, x, u, x0, J_cur, workspace, x_new, u_new, J_new, descent, stepsize,
-                                     ntrials, status);
+    return aoc32::api_newton_iterate(p, prm, kk, x, u, x0, J_cur, workspace, workspace_bytes, x_new, u_new, J_new, descent,
+                                     stepsize, ntrials, status);
 }
 
 }  // extern "C"

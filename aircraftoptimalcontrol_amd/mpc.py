@@ -117,7 +117,7 @@ class RecedingHorizon:
         slot = C.c_int32(0)
         check(lib().aoc_mpc_step(C.byref(p_track), C.byref(p_next), C.byref(self.prm), self.n_newton,
                                  _b._ptr(sv.xb[c]), _b._ptr(sv.ub[c]), _b._ptr(sv.x0), _b._ptr(self.x_true_d),
-                                 _b._ptr(dist_d), _b._ptr(sv.ws), _b._ptr(self.Kg), _b._ptr(sv.xb[a]), _b._ptr(sv.ub[a]),
+                                 _b._ptr(dist_d), _b._ptr(sv.ws), sv.ws.numel() * 8, _b._ptr(self.Kg), _b._ptr(sv.xb[a]), _b._ptr(sv.ub[a]),
                                  _b._ptr(sv.xb[b]), _b._ptr(sv.ub[b]), _b._ptr(sv.J[0]), _b._ptr(sv.J[1]),
                                  _b._ptr(sv.descent), _b._ptr(sv.stepsize), _b._ptr(sv.ntrials), _b._ptr(sv.status),
                                  _b._ptr(self.K0_d), _b._ptr(self.ua_d), C.byref(slot)), "aoc_mpc_step")

@@ -291,7 +291,9 @@ int aoc_ltv_lqr(int32_t nb, int32_t T, int32_t augmented, const double *A, const
                 int32_t *nreg, int32_t *nsing, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Iteration level.  Workspace: caller-allocated device memory of aoc_workspace_bytes(B,T) bytes.
+ * Iteration level.  Workspace: caller-allocated device memory of aoc_workspace_bytes(B,T) bytes; its size is passed
+ * along (`workspace_bytes`) and checked: too small a workspace is an AOC_EINVAL, not a memory fault.  (A workspace sized
+ * for B trajectories also serves any smaller batch.)
  * --------------------------------------------------------------------------------------------- */
 size_t aoc_workspace_bytes(int32_t B, int32_t T);
 
@@ -303,8 +305,8 @@ size_t aoc_workspace_bytes(int32_t B, int32_t T);
  * mode); convergence bookkeeping is the caller's (aoc_newton_solve does it). */
 int aoc_newton_iterate(const aoc_problem *prob, const aoc_params *prm, int32_t kk, const void *x,
                        const double *u, const double *x0, const double *J_cur, void *workspace,
-                       void *x_new, double *u_new, double *J_new, double *descent, double *stepsize,
-                       int32_t *ntrials, int32_t *status);
+                       size_t workspace_bytes, void *x_new, double *u_new, double *J_new, double *descent,
+                       double *stepsize, int32_t *ntrials, int32_t *status);
 
 /* ---------------------------------------------------------------------------------------------
  * Solve level: NewtonMethod.optimize (optcon.py:341-529) for every trajectory, termination included.
@@ -335,7 +337,7 @@ size_t aoc_solve_workspace_bytes(int32_t B, int32_t T);
  *   launching when it is 0.  *n_run (host, may be NULL): iterations launched.
  * workspace: aoc_solve_workspace_bytes(B,T) bytes of device memory. */
 int aoc_newton_solve(const aoc_problem *prob, const aoc_params *prm, const void *x_init, const double *u_init,
-                     const double *x0, void *workspace, int32_t sync_every, void *x_star, double *u_star,
+                     const double *x0, void *workspace, size_t workspace_bytes, int32_t sync_every, void *x_star, double *u_star,
                      int32_t *iters, int32_t *ret_index, int32_t *status, double *hist_cost,
                      double *hist_descent, double *hist_stepsize, int32_t *hist_ntrials, int32_t *n_run);
 
@@ -356,7 +358,7 @@ int aoc_newton_solve(const aoc_problem *prob, const aoc_params *prm, const void 
  * ([ntiles][2][64]): per-instance vectors laid out like x0.  workspace: aoc_workspace_bytes(B,T). */
 int aoc_mpc_step(const aoc_problem *prob_track, const aoc_problem *prob_next, const aoc_params *prm,
                  int32_t n_newton, const void *x_cur, const double *u_cur, double *x0, double *x_true,
-                 const double *disturbance, void *workspace, double *Kgain, void *x_a, double *u_a, void *x_b,
+                 const double *disturbance, void *workspace, size_t workspace_bytes, double *Kgain, void *x_a, double *u_a, void *x_b,
                  double *u_b, double *J_a, double *J_b, double *descent, double *stepsize, int32_t *ntrials,
                  int32_t *status, double *K0, double *u_applied, int32_t *final_slot);
 
@@ -376,8 +378,8 @@ int aoc_rollout_cost_f32(const aoc_problem *prob, const float *x0, const float *
 size_t aoc_workspace_bytes_f32(int32_t B, int32_t T);
 int aoc_newton_iterate_f32(const aoc_problem *prob, const aoc_params *prm, int32_t kk, const float *x,
                            const float *u, const float *x0, const float *J_cur, void *workspace,
-                           float *x_new, float *u_new, float *J_new, float *descent, float *stepsize,
-                           int32_t *ntrials, int32_t *status);
+                           size_t workspace_bytes, float *x_new, float *u_new, float *J_new, float *descent,
+                           float *stepsize, int32_t *ntrials, int32_t *status);
 
 #ifdef __cplusplus
 }

@@ -112,3 +112,17 @@ def test_argument_errors_carry_a_reason():
     p.T = 2
     assert lib.aoc_traj_cost(C.byref(p), 1, 1, 1, 1) == -1
     assert b"T = 2" in lib.aoc_last_hip_error()
+
+
+def test_too_small_a_workspace_is_an_error_not_a_fault():
+    """aoc_newton_iterate / aoc_newton_solve / aoc_mpc_step are told the size of their workspace and refuse one that is
+    too small before anything is launched."""
+    lib = _lib.lib()
+    p = _lib.Problem()
+    p.B, p.T, p.ref = 4096, 500, 1
+    prm = _lib.Params(200, 10, 1.0, 0.5, 0.7, -1e-6, 8, 0)
+    need = lib.aoc_workspace_bytes(4096, 500)
+    rc = lib.aoc_newton_iterate(C.byref(p), C.byref(prm), 0, 1, 1, 1, 1, 1, need // 100, 1, 1, 1, 1, 1, 1, 1)
+    assert rc == -1 and b"workspace" in lib.aoc_last_hip_error()
+    rc = lib.aoc_newton_solve(C.byref(p), C.byref(prm), 1, 1, 1, 1, 1000, 4, 1, 1, 1, 1, 1, None, None, None, None, None)
+    assert rc == -1 and b"workspace" in lib.aoc_last_hip_error()
