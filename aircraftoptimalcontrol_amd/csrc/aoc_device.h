@@ -70,26 +70,38 @@ struct SC { real sg, cg, sa, ca; };
 // [-pi/4, pi/4] (degree 13 / 14, < 1 ulp).  The library sincos() spends ~150 instructions per call,
 // mostly on a Payne-Hanek path these arguments never take; this one is ~45 and has no control flow,
 // so the two calls per stage interleave.  float32 arithmetic (config 3) uses the library's sincosf.
-__device__ __forceinline__ void sincos_fast(double x, double* sp, double* cp) {
-    const double n = __builtin_rint(x * 6.36619772367581382433e-01);          // x * 2/pi
-    double r = __builtin_fma(-n, 1.57079632679489655800e+00, x);               // pi/2, exact step
-    r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
-    r = __builtin_fma(-n, -1.49738490485916983689e-33, r);
+// The constants of the fp64 evaluation as a value: by default they fold back into literals (the compiler keeps them in
+// SGPRs or re-materialises them with s_mov pairs, which is free beside other wavefronts' vector work); pin() turns them
+// into VGPR residents for the small-batch kernels, see pin_consts().
+template <typename T> struct TrigK {};
+template <> struct TrigK<double> {
+    double t2p = 6.36619772367581382433e-01;                                     // 2/pi
+    double p1 = 1.57079632679489655800e+00, p2 = 6.12323399573676603587e-17, p3 = -1.49738490485916983689e-33;
+    double s5 = 1.58969099521155010221e-10, s4 = -2.50507602534068634195e-08, s3 = 2.75573137070700676789e-06,
+           s2 = -1.98412698298579493134e-04, s1 = 8.33333333332248946124e-03, s0 = -1.66666666666666324348e-01;
+    double c5 = -1.13596475577881948265e-11, c4 = 2.08757232129817482790e-09, c3 = -2.75573143513906633035e-07,
+           c2 = 2.48015872894767294178e-05, c1 = -1.38888888888741095749e-03, c0 = 4.16666666666666019037e-02;
+};
+__device__ __forceinline__ void sincos_fast(double x, double* sp, double* cp, const TrigK<double>& K = TrigK<double>()) {
+    const double n = __builtin_rint(x * K.t2p);                                 // x * 2/pi
+    double r = __builtin_fma(-n, K.p1, x);                                      // pi/2, exact step
+    r = __builtin_fma(-n, K.p2, r);
+    r = __builtin_fma(-n, K.p3, r);
     const int q = (int)n;
     const double z = r * r;
     // sin(r) = r + r z (S1 + z (S2 + ... ))
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    double ps = __builtin_fma(z, K.s5, K.s4);
+    ps = __builtin_fma(z, ps, K.s3);
+    ps = __builtin_fma(z, ps, K.s2);
+    ps = __builtin_fma(z, ps, K.s1);
+    ps = __builtin_fma(z, ps, K.s0);
     const double sr = __builtin_fma(r * z, ps, r);
     // cos(r) = 1 - z/2 + z^2 (C1 + z (C2 + ... )), summed so that the leading 1 - z/2 stays exact
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    double pc = __builtin_fma(z, K.c5, K.c4);
+    pc = __builtin_fma(z, pc, K.c3);
+    pc = __builtin_fma(z, pc, K.c2);
+    pc = __builtin_fma(z, pc, K.c1);
+    pc = __builtin_fma(z, pc, K.c0);
     const double hz = 0.5 * z, w = 1.0 - hz;
     const double cr = w + (((1.0 - w) - hz) + (z * z) * pc);
     // quadrant
@@ -106,7 +118,7 @@ __device__ __forceinline__ void sincos_fast(double x, double* sp, double* cp) {
 // float32 arithmetic (config 3): the same scheme in single precision — three-step Cody-Waite by pi/2, the
 // classic degree-7 / degree-8 kernels on [-pi/4, pi/4] (~1 ulp), branch-free; the library's sincosf (with its
 // large-argument path) only for finite |x| >= 2^17, see trig().
-__device__ __forceinline__ void sincos_fast(float x, float* sp, float* cp) {
+__device__ __forceinline__ void sincos_fast(float x, float* sp, float* cp, const TrigK<float>& = TrigK<float>()) {
     const float n = __builtin_rintf(x * 6.36619772367581382433e-01f);
     float r = __builtin_fmaf(-n, 1.57079625129699707031e+00f, x);
     r = __builtin_fmaf(-n, 7.54978941586159635335e-08f, r);
@@ -132,11 +144,11 @@ __device__ __forceinline__ void sincos_lib(float x, float* sp, float* cp) { sinc
 // interleave); ONE rarely-taken branch afterwards redoes them with the library for huge finite
 // arguments.  (A wave-uniform shortcut for |angle| <= pi/4, where the reduction is the
 // identity, was measured and bought nothing: the extra branch costs what the dozen instructions save.)
-__device__ __forceinline__ SC trig(real th, real ga) {
+__device__ __forceinline__ SC trig(real th, real ga, const TrigK<real>& K = TrigK<real>()) {
     SC s;
     const real al = th - ga;
-    sincos_fast(ga, &s.sg, &s.cg);
-    sincos_fast(al, &s.sa, &s.ca);
+    sincos_fast(ga, &s.sg, &s.cg, K);
+    sincos_fast(al, &s.sa, &s.ca, K);
     // finite and huge only: for NaN and +-inf the fast path already returns NaN, as sin/cos do.  (A diverged
     // trajectory is NaN from some stage on; sending it through the library made its wavefront the straggler
     // of the launch: 13 NaN trajectories in 65 536 cost the forward pass +55 %.)
@@ -147,6 +159,32 @@ __device__ __forceinline__ SC trig(real th, real ga) {
         sincos_lib(al, &s.sa, &s.ca);
     }
     return s;
+}
+
+// Small batches run ONE wavefront per SIMD.  That wavefront pays an issue slot for every instruction, scalar ones
+// included, and waits out every scalar load itself; with the ~50 uniform doubles of a rollout stage (model, weights,
+// polynomial coefficients) competing for ~100 SGPRs the compiler re-materialises literals with s_mov pairs and
+// re-loads kernel arguments inside the stage loop (60 of the 274 instructions of a rollout stage, ten scalar-load
+// waits).  pin_consts() moves the uniform doubles into VGPRs, which those kernels have to spare, behind an empty asm
+// the optimiser cannot see through: loaded once per kernel, same values, same arithmetic.
+__device__ __forceinline__ void vpin(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void vpin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin_trig(TrigK<double>& K) {
+    vpin(K.t2p); vpin(K.p1); vpin(K.p2); vpin(K.p3);
+    vpin(K.s5); vpin(K.s4); vpin(K.s3); vpin(K.s2); vpin(K.s1); vpin(K.s0);
+    vpin(K.c5); vpin(K.c4); vpin(K.c3); vpin(K.c2); vpin(K.c1); vpin(K.c0);
+}
+__device__ __forceinline__ void pin_trig(TrigK<float>&) {}
+template <bool DIAG>
+__device__ __forceinline__ void pin_consts(KConst& k) {
+    vpin(k.cd0); vpin(k.cda); vpin(k.cla); vpin(k.m); vpin(k.g); vpin(k.S); vpin(k.rho); vpin(k.J); vpin(k.dt);
+    vpin(k.dtm); vpin(k.mg); vpin(k.hrho); vpin(k.krs); vpin(k.b41); vpin(k.rJ);
+#pragma unroll
+    for (int i = 0; i < 36; i++)
+        if (!DIAG || i % 7 == 0) { vpin(k.Q[i]); vpin(k.QT[i]); }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (!DIAG || i % 3 == 0) vpin(k.R[i]);
 }
 
 // a / b for a wave-uniform b with rb = RN(1/b): q0 = RN(a rb), r = a - q0 b (exact, one fma), RN(q0 + r rb).

@@ -112,7 +112,7 @@ static void tuning_defaults(aoc_tuning* t) {
     t->ls_depth_min = env("AOC_LS_DEPTH_MIN", 2);
     t->fw_recompute = env("AOC_FW_RECOMPUTE", 1);
     t->store_candidates = env("AOC_STORE_CANDIDATES", 1);
-    t->bw5_tiles = env("AOC_BW5_TILES", 256);
+    t->bw4_tiles = env("AOC_BW4_TILES", 256);
 }
 
 static const aoc_tuning& tuning() {

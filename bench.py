@@ -78,7 +78,7 @@ def kernel_names(ntiles, full):
     wl = t.ls_worklist > 0 or (t.ls_worklist < 0 and ntiles > t.split_tiles)
     small = ntiles <= t.split_tiles
     return {
-        "backward": "k_backward5<true, false, float>" if (not full and ntiles <= min(t.bw5_tiles, t.split_bw_tiles)) else
+        "backward": "k_backward4<true, false, false, false, float>" if (not full and ntiles <= min(t.bw4_tiles, t.split_bw_tiles)) else
                     ("k_backward2<%s, float>" if ntiles <= t.split_bw_tiles else "k_backward<%s, float>") % fl,
         # <diagonal, shared reference, 2 speculated trials, states re-computed (the iterates of the run are rollouts), float32 states>
         "forward": "k_forward_split<true, false, float>" if small else

@@ -133,7 +133,7 @@ typedef struct aoc_tuning {
     int32_t fw_recompute;   /* AOC_FW_RECOMPUTE aoc_forward re-computes the states when aoc_problem.x_is_rollout allows it (1) */
     int32_t store_candidates; /* AOC_STORE_CANDIDATES aoc_newton_iterate: small batches keep the trajectories of the Armijo candidates
                                rolled out in the forward pass, the update then copies the accepted one (1) */
-    int32_t bw5_tiles;      /* AOC_BW5_TILES    Gauss-Newton backward pass on five wavefronts per tile (two producers, Riccati columns over three) up to this many tiles (256) */
+    int32_t bw4_tiles;      /* AOC_BW4_TILES    Gauss-Newton backward pass on four wavefronts per tile (one producer, Riccati columns over three) up to this many tiles (256) */
     int32_t reserved[2];
 } aoc_tuning;
 void aoc_get_tuning(aoc_tuning *out);

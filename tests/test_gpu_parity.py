@@ -711,9 +711,9 @@ def test_stored_candidates_do_not_change_results(aoc, tuned):
         assert any((h["status"] & _lib.ST_ARMIJO_EXH).any() for h in ha), "the run should contain exhausted searches"
 
 
-def test_five_wavefront_backward_equals_the_others(aoc, tuned):
-    """Tiny batches run the Gauss-Newton backward pass on five wavefronts per tile (k_backward5: two producers taking
-    the stages in turn, the Riccati columns {0,1,2}, {3,4}, {5} + affine terms on three consumers).  Against the
+def test_four_wavefront_backward_equals_the_others(aoc, tuned):
+    """Tiny batches run the Gauss-Newton backward pass on four wavefronts per tile (k_backward4: one producer, the Riccati
+    columns {0,1,2}, {3,4}, {5} + affine terms on three consumers, constants pinned in VGPRs).  Against the
     two-wavefront and the one-wavefront kernel: gains, direction, descent and every iterate over 12 iterations bit for
     bit (the full-Hessian iterations run k_backward2 in every variant), incl. a golden Gauss-Newton case."""
     from aircraftoptimalcontrol_amd import problems
@@ -722,7 +722,7 @@ def test_five_wavefront_backward_equals_the_others(aoc, tuned):
     B = 150
     x0 = problems.random_x0(B, seed=23)
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
-    variants = (dict(bw5_tiles=256), dict(bw5_tiles=0), dict(bw5_tiles=0, split_bw_tiles=0))
+    variants = (dict(bw4_tiles=256), dict(bw4_tiles=0), dict(bw4_tiles=0, split_bw_tiles=0))
     res = []
     for kn in variants:
         tuned(**kn)
