@@ -621,18 +621,19 @@ def test_split_kernels_equal_single_wavefront_kernels(aoc, tuned):
         res.append((s.run_fixed(11), s.current()))
     (ha, (xa, ua)), (hb, (xb, ub)) = res
     assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(ua, ub, equal_nan=True)
-    # the same for the tracking gains and the stored-state rollout (k_track_gains2, k_rollout_cost_split)
+    # the same for the tracking gains and the stored-state rollout (k_track_gains2/4, k_rollout_cost_split)
     tw = problems.tracking_weights()
     tp = aoc.BatchProblem(tw[0], tw[1], tw[2], pr.xx_ref, pr.uu_ref, pr.dt)
     outs = []
-    for tiles in (0, 512):
-        tuned(split_tiles=tiles)
+    for kn in (dict(split_tiles=0), dict(split_tiles=512, bw4_tiles=0), dict(split_tiles=512, bw4_tiles=256)):
+        tuned(**kn)   # k_track_gains / k_track_gains2 / k_track_gains4
         g = aoc.lqr_tracking_batch(tp, xa[:70], ua[:70], 0.1)
         r = aoc.rollout_cost(bp, x0[:70], ua[:70], du=0.3 * ua[:70], alpha=np.full(70, 0.7))
         outs.append((g, r))
-    (ga, ra), (gb, rb) = outs
-    for a_, b_ in list(zip(ga, gb)) + list(zip(ra, rb)):
-        assert np.array_equal(a_, b_, equal_nan=True)
+    ga, ra = outs[0]
+    for gb, rb in outs[1:]:
+        for a_, b_ in list(zip(ga, gb)) + list(zip(ra, rb)):
+            assert np.array_equal(a_, b_, equal_nan=True)
     for a, b in zip(ha, hb):
         for key in ("stepsize", "ntrials", "cost", "cost_new", "descent", "status"):
             assert np.array_equal(a[key], b[key], equal_nan=True), key
