@@ -339,6 +339,16 @@ class NewtonBatchSolver:
         return ev
 
     # -- results ---------------------------------------------------------------------------------
+    def direction(self):
+        """du (B,2,T) of the last iteration (it stays in the workspace until the next one)."""
+        nel14 = lib().aoc_tiled_elems(self.B, self.T, 14)
+        nel2 = lib().aoc_tiled_elems(self.B, self.T, 2)
+        return unpack(self.ws[nel14:nel14 + nel2].view(self.nt, self.T, 2, TILE), self.B).cpu().numpy()
+
+    def previous_inputs(self):
+        """uu (B,2,T) of the iterate the last iteration started from (the buffers rotate over three slots)."""
+        return unpack(self.ub[(self.cur - 1) % 3], self.B).cpu().numpy()
+
     def _unpack_iterate(self, i):
         """(B,6,T), (B,2,T) fp64 device tensors of buffer i, sample 0 restored from the fp64 x0."""
         if self.cur_is64 and i == self.cur:

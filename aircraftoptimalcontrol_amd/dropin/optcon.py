@@ -5,8 +5,11 @@
 Same constructor arguments, method names, return values and stdout lines as the reference
 (file:line cited per method).  The Dynamics/Cost objects passed in must be the drop-in
 `aircraft_simplified.Dynamics` / `Cost` (the HIP kernels implement that model and a quadratic cost);
-anything else raises TypeError.  Differences, all outside the numerical path: no Matplotlib figures
-are opened (histories are kept on the object instead: `.JJ`, `.descent`, `.stepsizes`), and
+anything else raises TypeError.  Differences, all outside the numerical path: the cost / descent figures the
+reference opens at the end of `optimize` (optcon.py:513-528) are drawn on request (`plot_histories()`; the histories
+are kept on the object: `.JJ`, `.descent`, `.stepsizes`); `visu_armijo=True` evaluates and records the reference's
+Armijo figure per iteration (`.armijo_curves`, optcon.py:280-325) and draws it when Matplotlib is importable
+(non-blocking; saved under $AOC_PLOT_DIR if that is set); and
 `GradientMethod.optimize`, which raises TypeError in the reference (8 arguments passed to a
 9-parameter method, optcon.py:125 vs :204), runs here with the missing argument supplied (parity unpinned).
 """
@@ -44,6 +47,67 @@ class GradientMethod:
         self.visu_armijo = visu_armijo
 
     # -- helpers -------------------------------------------------------------------------------
+    def _armijo_figure(self, prob, uu, deltau, x0, JP, descent, n_tested, tag):
+        """The reference's Armijo plot (optcon.py:280-325): cost along the search direction at
+        linspace(0, stepsize_0, armijo_maxiters), the tangent JP + descent*step, the Armijo line JP + cc*descent*step
+        and the steps that were tested — all rollouts in two launches.  Recorded in self.armijo_curves; drawn on
+        figure 1 when Matplotlib is there."""
+        n = int(self.armijo_maxiters)
+        steps = np.linspace(0, self.stepsize_0, n)
+        tested = [self.stepsize_0]
+        for _ in range(max(n_tested - 1, 0)):
+            tested.append(self.beta * tested[-1])
+        tested = np.array(tested[:n_tested])
+        al = np.concatenate([steps, tested])
+        rep = lambda a: np.repeat(np.asarray(a, dtype=np.float64)[None], len(al), 0)
+        _, _, J, _ = _b.rollout_cost(prob, rep(x0), rep(uu), rep(deltau), al, write=False)
+        rec = dict(tag=tag, steps=steps, costs=J[:n].copy(), JP=float(JP), descent=float(descent), cc=self.cc,
+                   stepsizes=tested, costs_armijo=J[n:].copy())
+        if not hasattr(self, "armijo_curves"):
+            self.armijo_curves = []
+        self.armijo_curves.append(rec)
+        try:
+            import matplotlib.pyplot as plt
+        except ImportError:
+            return rec
+        plt.figure(1)
+        plt.clf()
+        plt.plot(steps, rec["costs"], color='g', label='$J(\\mathbf{u}^k - stepsize*d^k)$')
+        plt.plot(steps, JP + descent * steps, color='r',
+                 label='$J(\\mathbf{u}^k) - stepsize*\\nabla J(\\mathbf{u}^k)^{\\top} d^k$')
+        plt.plot(steps, JP + self.cc * descent * steps, color='g', linestyle='dashed',
+                 label='$J(\\mathbf{u}^k) - stepsize*c*\\nabla J(\\mathbf{u}^k)^{\\top} d^k$')
+        plt.scatter(tested, rec["costs_armijo"], marker='*')   # the tested stepsizes
+        plt.grid()
+        plt.xlabel('stepsize')
+        plt.legend()
+        plt.draw()
+        import os
+        d = os.environ.get("AOC_PLOT_DIR")
+        if d:
+            os.makedirs(d, exist_ok=True)
+            plt.savefig(os.path.join(d, "armijo_%s.png" % tag))
+        return rec
+
+    def plot_histories(self):
+        """The two figures the reference opens at the end of optimize (optcon.py:513-528): -descent and cost over the
+        iterations, log scale.  Needs Matplotlib; returns the two figures."""
+        import matplotlib.pyplot as plt
+        n = len(self.JJ)
+        f1 = plt.figure('descent direction')
+        plt.plot(np.arange(n), -np.asarray(self.descent))
+        plt.xlabel('$k$')
+        plt.ylabel('||$\\nabla J(\\mathbf{u}^k)||$')
+        plt.yscale('log')
+        plt.grid()
+        f2 = plt.figure('cost')
+        plt.plot(np.arange(n), np.asarray(self.JJ))
+        plt.xlabel('$k$')
+        plt.ylabel('$J(\\mathbf{u}^k)$')
+        plt.yscale('log')
+        plt.grid()
+        return f1, f2
+
     def _problem(self, TT):
         mdl = _model_of(self.dyn)
         Q, R, QT = _weights_of(self.cst)
@@ -108,11 +172,15 @@ class GradientMethod:
                                      np.repeat(np.asarray(deltau, dtype=np.float64)[None], n, 0),
                                      np.array(steps[:n]), write=False)
         JP, descent = float(np.squeeze(JP)), float(np.squeeze(descent))
+        accepted = n
         for ii in range(n):
             if not (J[ii] > JP + self.cc * steps[ii] * descent):
                 print('Armijo stepsize = {}'.format(steps[ii]))
-                return steps[ii]
-        return steps[n]
+                accepted = ii
+                break
+        if self.visu_armijo:
+            self._armijo_figure(prob, uu, deltau, x0, JP, descent, min(accepted + 1, n), "call%d" % len(getattr(self, "armijo_curves", [])))
+        return steps[accepted]
 
 
 class NewtonMethod(GradientMethod):
@@ -131,7 +199,12 @@ class NewtonMethod(GradientMethod):
         for _ in range(int(self.armijo_maxiters)):
             exhausted = self.beta * exhausted               # the step an exhausted search returns (optcon.py:327)
 
+        x0 = np.asarray(xx_init, dtype=np.float64)[:, 0]
+
         def echo(kk, sc):
+            if self.visu_armijo:                            # optcon.py:280-325, after the search of this iteration
+                self._armijo_figure(prob, s.previous_inputs()[0], s.direction()[0], x0, float(sc["cost"][0]),
+                                    float(sc["descent"][0]), int(sc["ntrials"][0]), "iter%d" % kk)
             if float(sc["stepsize"][0]) != exhausted:       # accepted trials print, exhausted searches do not
                 print('Armijo stepsize = {}'.format(float(sc["stepsize"][0])))   # optcon.py:272
             print('Iter = {}\t Descent = {}\t Cost = {}'.format(kk, float(sc["descent"][0]), float(sc["cost"][0])))

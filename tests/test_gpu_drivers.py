@@ -89,3 +89,42 @@ def test_run_batch(tmp_path):
     assert m and int(m.group(1)) == 700 and int(m.group(2)) > 600 and 10 <= int(m.group(4)) <= 30
     c = re.search(r"cost first/last \(mean\): (\S+) -> (\S+)", out)
     assert float(c.group(2)) < float(c.group(1))
+
+
+def test_visu_armijo_records_the_references_figure(tmp_path, monkeypatch):
+    """NewtonMethod(..., visu_armijo=True): the reference's Armijo figure (optcon.py:280-325) — cost along the search
+    direction at linspace(0, stepsize_0, armijo_maxiters), the tested steps — per iteration, against the oracle's
+    get_update + cost on the same direction; the figure files and the two history figures (optcon.py:513-528)."""
+    monkeypatch.setenv("MPLBACKEND", "Agg")
+    monkeypatch.setenv("AOC_PLOT_DIR", str(tmp_path))
+    sys.path.insert(0, os.path.join(ROOT, "aircraftoptimalcontrol_amd", "dropin"))
+    try:
+        import optcon
+        import aircraft_simplified
+    finally:
+        sys.path.pop(0)
+    from aircraftoptimalcontrol_amd import problems
+    from oracle import oracle as orc
+    pr = problems.step_maneuver(1.0, 2e-3)
+    dyn = aircraft_simplified.Dynamics()
+    dyn.dt = pr.dt
+    cst = aircraft_simplified.Cost(pr.QQt, pr.RRt, pr.QQT)
+    nm = optcon.NewtonMethod(dyn, cst, pr.xx_ref, pr.uu_ref, max_iters=4, stepsize_0=1, cc=0.5, beta=0.7,
+                             armijo_maxiters=10, visu_armijo=True)
+    xx0, uu0 = dyn.get_initial_trajectory(pr.xx_ref, pr.tt)
+    nm.optimize(xx0, uu0, pr.tf, pr.dt)
+    assert len(nm.armijo_curves) == 3
+    op = orc.OracleProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    for kk, rec in enumerate(nm.armijo_curves):
+        assert rec["steps"].shape == (10,) and rec["steps"][0] == 0 and rec["steps"][-1] == 1
+        assert rec["costs"][0] == rec["JP"] == nm.JJ[kk]           # step 0: the cost of the iterate itself (Q10)
+        assert rec["costs_armijo"][-1] <= rec["JP"] + 0.5 * rec["stepsizes"][-1] * rec["descent"]   # the accepted trial
+        assert os.path.exists(os.path.join(tmp_path, "armijo_iter%d.png" % kk))
+    # the curve of iteration 0 against the oracle: same direction, the reference's rollout and cost
+    r = orc.newton_iterate(op, orc.params(), 0, xx0[:, :pr.T], uu0[:, :pr.T], xx0[:, 0], want_internals=True)
+    rec = nm.armijo_curves[0]
+    for ii in (3, 9):
+        xo, uo = orc.get_update(op, float(rec["steps"][ii]), uu0[:, :pr.T], r["du"], xx0[:, 0])
+        assert abs(orc.traj_cost(op, xo, uo) - rec["costs"][ii]) <= 1e-9 * abs(rec["costs"][ii])
+    f1, f2 = nm.plot_histories()
+    assert len(f1.axes[0].lines) == 1 and len(f2.axes[0].lines) == 1
