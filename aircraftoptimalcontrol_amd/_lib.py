@@ -86,7 +86,7 @@ SYMBOLS = {
     "aoc_rollout_cost": (C.c_int, [_P] * 9),
     "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
     "aoc_gradient": (C.c_int, [_P] * 7),
-    "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 9),
+    "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 10),
     "aoc_candidate_bytes": (_Z, [_I, _I, _I]),
     "aoc_linesearch_scratch_bytes": (_Z, [_I, _I]),
     "aoc_spec_max": (_I, []),

@@ -133,6 +133,14 @@ def unpack(tiled, B):
     return dst
 
 
+def unpack_gains(Kt, B):
+    """K~ as aoc_backward writes it — per tile and sample seven columns, the two rows of a column side by side:
+    [ntiles][T][7][64][2] — -> (B,2,7,T) fp64 torch tensor on the device (the reference's KK[:, :, t], optcon.py:751)."""
+    nt, T = Kt.shape[0], Kt.shape[1]
+    v = Kt.reshape(nt, T, 7, TILE, 2)
+    return v.permute(0, 3, 4, 2, 1).reshape(nt * TILE, 2, 7, T)[:B]
+
+
 def unpack_vec(v, B):
     """[ntiles][C][64] -> (B,C)"""
     return v.permute(0, 2, 1).reshape(-1, v.shape[1])[:B]
@@ -323,8 +331,8 @@ class NewtonBatchSolver:
                                  _ptr(Kt), None, _ptr(self.status)), "aoc_backward")
         ev[1].record(st)
         check(lib().aoc_forward(C.byref(p), C.byref(prm), nsp, _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
-                                _ptr(Kt), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status), _ptr(cand)),
-              "aoc_forward")
+                                _ptr(Kt), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status), _ptr(cand),
+                                _ptr(self.ntrials)), "aoc_forward")
         ev[2].record(st)
         check(lib().aoc_linesearch_search(C.byref(p), C.byref(prm), nsp, _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
                                           _ptr(self.J[jc]), _ptr(self.descent), _ptr(Jt), _ptr(self.stepsize),
@@ -737,8 +745,8 @@ def backward_forward(problem, xx, uu, full_hessian, stepsize_0=1.0, f32=False):
                              _ptr(lm0), _ptr(st)), "aoc_backward")
     prm = make_params(stepsize_0=stepsize_0)
     check(lib().aoc_forward(C.byref(p), C.byref(prm), 1, _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(du),
-                            _ptr(desc), _ptr(Jn), _ptr(st), None), "aoc_forward")
-    KK = unpack(Kt, B).cpu().numpy().reshape(B, 2, 7, T)
+                            _ptr(desc), _ptr(Jn), _ptr(st), None, None), "aoc_forward")
+    KK = unpack_gains(Kt, B).cpu().numpy()
     return dict(KK=KK, du=unpack(du, B).cpu().numpy(),
                 descent=desc[:B].cpu().numpy(), lmbd0=unpack_vec(lm0, B).cpu().numpy(),
                 J_trial0=Jn[:B].cpu().numpy(), status=st[:B].cpu().numpy())

@@ -285,8 +285,8 @@ int aoc_gradient(const aoc_problem* p, const void* x, const double* u, const dou
 }
 int aoc_forward(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const void* x, const double* u,
                 const double* x0, const double* Kt, double* du, double* descent, double* J_trial, int32_t* status,
-                void* cand) {
-    return aoc64::api_forward(p, prm, n_spec, x, u, x0, Kt, du, descent, J_trial, status, cand);
+                void* cand, const int32_t* ntrials_hint) {
+    return aoc64::api_forward(p, prm, n_spec, x, u, x0, Kt, du, descent, J_trial, status, cand, ntrials_hint);
 }
 size_t aoc_candidate_bytes(int32_t B, int32_t T, int32_t n_spec) {
     return B >= 1 && T >= 1 && n_spec >= 1 ? aoc64::cand_bytes(B, T, n_spec) : 0;

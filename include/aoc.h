@@ -194,8 +194,10 @@ int aoc_rollout_cost(const aoc_problem *prob, const double *x0, const double *u,
 /* Backward pass of one Newton iteration: terminal condition, quadratisation (Gauss-Newton, or full
  * Hessian with the costate sweep lambda_t = A^T lambda_{t+1} + l_x, optcon.py:461) and the affine
  * Riccati/gain recursion of ltv_LQR, fused (optcon.py:429-464 + :655-751).  Writes per stage the gain
- * K~ (2x7: column 0 feed-forward sigma, columns 1..6 feedback K) as 14 components.
- * Kt: tiled C=14 over T samples (sample T-1 unused).
+ * K~ (2x7: column 0 feed-forward sigma, columns 1..6 feedback K), stored column by column with the two rows of a
+ * column side by side (one 16-byte access per column and lane):
+ * Kt: [ntiles][T][7][64][2] doubles, elem(b,t,p,row) at ((((b/64)*T + t)*7 + p)*64 + b%64)*2 + row — the size of a
+ * tiled C=14 array, aoc_tiled_elems(B,T,14); sample T-1 unused.
  * lmbd0 (optional, [ntiles][6][64]) receives lambda_0 (forces the costate sweep). */
 int aoc_backward(const aoc_problem *prob, int32_t full_hessian, const void *x, const double *u,
                  const double *x0, double *Kt, double *lmbd0, int32_t *status);
@@ -223,11 +225,13 @@ int aoc_gradient(const aoc_problem *prob, const void *x, const double *u, const 
  * aoc_candidate_bytes(B, T, n_spec) bytes in which every trial keeps the trajectory it rolls out (x' as float32, u',
  * flags); handed to aoc_linesearch / aoc_linesearch_update together with n_spec and J_trial, the update of a tile whose
  * trajectories all accepted one of these candidates is a copy, parallel over the horizon, instead of one more serial
- * rollout — the same values either way. */
+ * rollout — the same values either way.  ntrials_hint (may be NULL): the trial counts of the previous iteration (the
+ * `ntrials` array aoc_linesearch filled; zeros = none): a tile then stores only as many candidates as its trajectories
+ * needed last time plus two, and the update falls back to the rollout for a tile that needed more. */
 size_t aoc_candidate_bytes(int32_t B, int32_t T, int32_t n_spec);
 int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const void *x, const double *u,
                 const double *x0, const double *Kt, double *du, double *descent, double *J_trial,
-                int32_t *status, void *cand);
+                int32_t *status, void *cand, const int32_t *ntrials_hint);
 
 /* Armijo back-tracking (optcon.py:243-273) and the final update (optcon.py:488-491).
  * Trial ii uses alpha_ii = stepsize_0*beta^ii and is accepted iff J'(alpha_ii) <= J_cur +

@@ -36,7 +36,7 @@ def test_geometry_helpers_and_errors():
     # small batches with at most one forward workgroup per CU keep the candidate trajectories; the region is sized for the
     # largest need of any batch up to B, because aoc_newton_solve runs its smaller generations in the same workspace
     assert lib.aoc_workspace_bytes(64, 500) == base(64) + lib.aoc_candidate_bytes(64, 500, lib.aoc_spec_max())
-    assert lib.aoc_candidate_bytes(64, 500, 10) == 10 * (64 * 500 * 48 + 64 * 4)
+    assert lib.aoc_candidate_bytes(64, 500, 10) == 10 * (64 * 500 * 48 + 64 * 4) + 16   # records, flags, stored count per tile
     sizes = [lib.aoc_workspace_bytes(B, 500) for B in (1, 64, 65, 1000, 4096, 6000, 8192, 8193, 40000, 131072)]
     assert sizes == sorted(sizes)
     assert lib.aoc_workspace_bytes(131072, 500) - base(131072) == max(lib.aoc_workspace_bytes(64 * t, 500) - base(64 * t) for t in range(1, 257))
