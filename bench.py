@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=131072)
     ap.add_argument("--horizon", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the small configs reported beside the headline")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream; the timed region itself carries the per-pass HIP events")
     return ap.parse_args()
@@ -106,6 +107,47 @@ def oracle_sample(pr, x0, iters, cores):
     t0 = time.time()
     h = orc.newton_iterate_batch(op, prm, XI, UI, XI[:, :, 0].copy(), 0, iters, nthreads=cores)
     return n, time.time() - t0, XI, UI, h
+
+
+def secondary_configs(torch, batch, problems, T):
+    """The small BASELINE configs at their per-GPU size, beside the headline (a few seconds): configs[1] = 4096
+    perturbed step-maneuver trajectories, 10 Newton iterations from the P-controller guess; configs[4] = 1024
+    receding-horizon instances x 50 warm-started re-solves of 2 Newton iterations feeding tracking gains."""
+    import time
+    from aircraftoptimalcontrol_amd import mpc
+    out = {}
+    pr = problems.step_maneuver(tf=1.0, dt=1.0 / T)
+    bp = batch.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    Bs = 4096
+    s = batch.NewtonBatchSolver(bp, Bs, batch.make_params(stepsize_0=1.0, armijo_maxiters=10))
+    x0 = problems.perturbed_x0(pr, Bs, seed=20260401)
+    best = None
+    for rep in range(3):
+        s.set_initial_from_x0(x0)
+        s.ntrials.zero_()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for kk in range(10):
+            s.iterate(kk)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["configs[1]"] = {"workload": "4096 step-maneuver trajectories (perturbed x0), T=%d, fp64, Newton iterations kk=0..9" % T,
+                         "ms_per_iteration": best / 10 * 1e3, "trajectory_iterations_per_s": Bs * 10 / best}
+    steps, Bm = 50, 1024
+    L = T + steps + 10
+    full = problems.step_maneuver(tf=1.0, dt=1.0 / L)
+    prm_ = problems.ProblemData("mpc", full.QQt, full.RRt, full.QQT, full.xx_ref, full.uu_ref, full.tt, full.tf, full.dt)
+    rh = mpc.RecedingHorizon(prm_, problems.tracking_weights(), Bm, T, n_newton=2,
+                             sigma=np.array([0.02, 0.02, 0.02, 0.002, 0.004, 0.002]))
+    rh.start(problems.perturbed_x0(prm_, Bm, seed=1), cold_iters=10)
+    rh.step(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        rh.step(fetch=False)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    out["configs[4]"] = {"workload": "1024 receding-horizon instances (per-GPU share of 8192), T=%d, %d re-solves x 2 Newton "
+                                     "iterations + tracking gains + plant step, all on the device" % (T, steps),
+                         "ms_per_receding_horizon_step": dt / steps * 1e3, "instance_steps_per_s": Bm * steps / dt}
+    return out
 
 
 def cpu_baseline(pr, x0, iters):
@@ -294,6 +336,11 @@ def run(a):
             out["cpu_baseline_error"] = repr(e)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if rank == 0 and world == 1 and not a.no_secondary and a.batch_per_gpu == 131072:
+        try:
+            out["secondary"] = secondary_configs(torch, batch, problems, a.horizon)
+        except Exception as e:  # a report beside the headline, never a reason to lose the bench line
+            out["secondary_error"] = repr(e)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
