@@ -85,7 +85,7 @@ def kernel_names(ntiles, full):
         "forward": "k_forward_split<true, false, float>" if small else
                    "k_forward<true, false, 2, %s, float>" % ("true" if t.fw_recompute else "false"),
         "linesearch_update": "k_ls_final_split<true, false, float>" if small else "k_ls_final<true, false, float>",
-        "linesearch_search": ("phase: k_ls_init_wl, k_ls_plan_wl, k_ls_trial_wl<true, false, %d> x2, k_ls_replan" % max(t.ls_cpl, 1)) if wl
+        "linesearch_search": ("phase: k_ls_init_wl, k_ls_plan_wl, k_ls_trial_wl<true, false, %d, pinned|plain> x2, k_ls_replan" % max(t.ls_cpl, 1)) if wl
         else "phase: k_ls_init, k_ls_plan, k_ls_trial*, k_ls_resolve (round-based search)",
     }
 
