@@ -86,14 +86,15 @@ SYMBOLS = {
     "aoc_rollout_cost": (C.c_int, [_P] * 9),
     "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
     "aoc_gradient": (C.c_int, [_P] * 7),
-    "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 10),
+    "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 9 + [_Z, _P]),
     "aoc_candidate_bytes": (_Z, [_I, _I, _I]),
+    "aoc_default_ncand": (_I, [_I, _I, _I]),
     "aoc_linesearch_scratch_bytes": (_Z, [_I, _I]),
     "aoc_spec_max": (_I, []),
     "aoc_default_nspec": (_I, [_I, _I]),
-    "aoc_linesearch": (C.c_int, [_P, _P, _I] + [_P] * 14),
-    "aoc_linesearch_search": (C.c_int, [_P, _P, _I] + [_P] * 9),
-    "aoc_linesearch_update": (C.c_int, [_P] * 12 + [_I, _P, _P]),
+    "aoc_linesearch": (C.c_int, [_P, _P, _I] + [_P] * 13 + [_Z, _P, _Z]),
+    "aoc_linesearch_search": (C.c_int, [_P, _P, _I] + [_P] * 9 + [_Z]),
+    "aoc_linesearch_update": (C.c_int, [_P] * 12 + [_Z, _I, _P, _P, _Z]),
     "aoc_lqr_tracking": (C.c_int, [_P] * 9),
     "aoc_ltv_lqr": (C.c_int, [_I, _I, _I] + [_P] * 17),
     "aoc_workspace_bytes": (_Z, [_I, _I]),

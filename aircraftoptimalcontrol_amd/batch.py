@@ -229,12 +229,16 @@ class NewtonBatchSolver:
         self.ntrials = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         self.status = torch.zeros(self.Bp, dtype=torch.int32, device=dev)
         self.x0 = torch.zeros((self.nt, 6, TILE), dtype=torch.float64, device=dev)
-        # Armijo trials riding along in the forward pass: what aoc_newton_iterate uses for this batch size
-        self.n_spec = int(lib().aoc_default_nspec(self.B, int(self.params.armijo_maxiters)))
         self.spec_max = int(lib().aoc_spec_max())
         self.cur = 0      # index of the buffer holding the current iterate
         self.kk = 0       # outer-iteration index of the current iterate
         self.jcur = 0
+
+    @property
+    def n_spec(self):
+        """Armijo trials riding along in the forward pass: what aoc_newton_iterate uses for this batch size under the
+        aoc_tuning of the moment."""
+        return int(lib().aoc_default_nspec(self.B, int(self.params.armijo_maxiters)))
 
     # -- problem struct with the current stream and the element types of this call's state arrays
     def _p(self, x_in_f32=1, x_out_f32=1):
@@ -299,6 +303,31 @@ class NewtonBatchSolver:
 
     PASSES = ("backward", "forward", "linesearch_search", "linesearch_update")
 
+    def _carve(self):
+        """The workspace as aoc_newton_iterate lays it out: K~ | du | trial costs | line-search scratch | candidate store
+        -> (Kt, du, J_trial, scratch, scratch bytes, n_spec, cand or None, cand bytes).  n_spec and the number of stored
+        candidates are asked from the library at call time (aoc_default_nspec / aoc_default_ncand follow aoc_tuning), and
+        the candidate store is handed over only if the workspace has room for it — as aoc_newton_iterate decides."""
+        l = lib()
+        nel14 = l.aoc_tiled_elems(self.B, self.T, 14)
+        nel2 = l.aoc_tiled_elems(self.B, self.T, 2)
+        Kt, du = self.ws[:nel14], self.ws[nel14:nel14 + nel2]
+        o = nel14 + nel2
+        Jt = self.ws[o:o + self.spec_max * self.Bp]
+        o += self.spec_max * self.Bp
+        scratch = self.ws[o:]
+        sbytes = int(l.aoc_linesearch_scratch_bytes(self.B, self.T))
+        sb = (sbytes + 255) // 256 * 256
+        nsp = int(l.aoc_default_nspec(self.B, int(self.params.armijo_maxiters)))
+        ncand = int(l.aoc_default_ncand(self.B, nsp, int(self.params.armijo_maxiters)))
+        cbytes = int(l.aoc_candidate_bytes(self.B, self.T, ncand)) if ncand else 0
+        cand = None
+        if ncand and sb + cbytes <= scratch.numel() * 8:
+            cand = scratch[sb // 8:]
+        else:
+            cbytes = 0
+        return Kt, du, Jt, scratch, sbytes, nsp, cand, cbytes
+
     def iterate_timed(self, kk=None):
         """The launches of iterate(), issued pass by pass with HIP events recorded on the launch
         stream between them: backward | forward | line-search rounds (aoc_linesearch_search) | final rollout
@@ -312,18 +341,7 @@ class NewtonBatchSolver:
         prm = self.params
         c, n = self.cur, (self.cur + 1) % 3
         jc, jn = self.jcur, 1 - self.jcur
-        nel14 = lib().aoc_tiled_elems(self.B, self.T, 14)
-        nel2 = lib().aoc_tiled_elems(self.B, self.T, 2)
-        Kt, du = self.ws[:nel14], self.ws[nel14:nel14 + nel2]
-        nsp = self.n_spec
-        Jt = self.ws[nel14 + nel2:nel14 + nel2 + self.spec_max * self.Bp]
-        scratch = self.ws[nel14 + nel2 + self.spec_max * self.Bp:]
-        # candidate store behind the line-search scratch, as aoc_newton_iterate lays it out (small batches only)
-        sb = (lib().aoc_linesearch_scratch_bytes(self.B, self.T) + 255) // 256 * 256
-        tn = _lib.Tuning()
-        lib().aoc_get_tuning(C.byref(tn))
-        stored = nsp > 3 and nsp >= prm.armijo_maxiters and self.nt * ((nsp + 2) // 3) <= 256   # as aoc_newton_iterate decides
-        cand = scratch[sb // 8:] if stored and tn.store_candidates else None
+        Kt, du, Jt, scratch, sbytes, nsp, cand, cbytes = self._carve()
         st = torch.cuda.current_stream(self.problem.device)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record(st)
@@ -331,17 +349,17 @@ class NewtonBatchSolver:
                                  _ptr(Kt), None, _ptr(self.status)), "aoc_backward")
         ev[1].record(st)
         check(lib().aoc_forward(C.byref(p), C.byref(prm), nsp, _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
-                                _ptr(Kt), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status), _ptr(cand),
+                                _ptr(Kt), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status), _ptr(cand), cbytes,
                                 _ptr(self.ntrials)), "aoc_forward")
         ev[2].record(st)
         check(lib().aoc_linesearch_search(C.byref(p), C.byref(prm), nsp, _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
                                           _ptr(self.J[jc]), _ptr(self.descent), _ptr(Jt), _ptr(self.stepsize),
-                                          _ptr(self.ntrials), _ptr(scratch)), "aoc_linesearch_search")
+                                          _ptr(self.ntrials), _ptr(scratch), sbytes), "aoc_linesearch_search")
         ev[3].record(st)
         check(lib().aoc_linesearch_update(C.byref(p), C.byref(prm), _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
                                           _ptr(self.xb[n]), _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.stepsize),
-                                          _ptr(self.ntrials), _ptr(self.status), _ptr(scratch), nsp, _ptr(Jt), _ptr(cand)),
-              "aoc_linesearch_update")
+                                          _ptr(self.ntrials), _ptr(self.status), _ptr(scratch), sbytes, nsp, _ptr(Jt),
+                                          _ptr(cand), cbytes), "aoc_linesearch_update")
         ev[4].record(st)
         self.cur, self.jcur, self.kk, self.cur_is64, self.cur_rollout = n, jn, kk + 1, False, True
         return ev
@@ -404,7 +422,7 @@ class NewtonBatchSolver:
         torch = _torch()
         n, dev = self.B, self.problem.device
         m = int(keep.numel())
-        nw = NewtonBatchSolver(self.problem, m, self.params)
+        nw = type(self)(self.problem, m, self.params)   # a GradientBatchSolver stays one (its iterate() differs)
         st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         for src, dst in (((self.cur - 1) % 3, 0), (self.cur, 1)):   # previous -> slot 0, current -> slot 1
             xs = unpack(self.xb[src], n)[keep].contiguous()
@@ -579,16 +597,13 @@ class GradientBatchSolver(NewtonBatchSolver):
         p = self._p(f32)
         c, n = self.cur, (self.cur + 1) % 3
         jc, jn = self.jcur, 1 - self.jcur
-        nel14 = lib().aoc_tiled_elems(self.B, self.T, 14)
-        nel2 = lib().aoc_tiled_elems(self.B, self.T, 2)
-        du = self.ws[nel14:nel14 + nel2]
-        scratch = self.ws[nel14 + nel2 + self.spec_max * self.Bp:]
+        _, du, _, scratch, sbytes, _, _, _ = self._carve()
         check(lib().aoc_gradient(C.byref(p), _ptr(x), _ptr(self.ub[c]), _ptr(self.x0), _ptr(du), _ptr(self.descent),
                                  _ptr(self.status)), "aoc_gradient")
         check(lib().aoc_linesearch(C.byref(p), C.byref(self.params), 0, _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
                                    _ptr(self.J[jc]), _ptr(self.descent), None, _ptr(self.xb[n]), _ptr(self.ub[n]),
                                    _ptr(self.J[jn]), _ptr(self.stepsize), _ptr(self.ntrials), _ptr(self.status),
-                                   _ptr(scratch), None), "aoc_linesearch")
+                                   _ptr(scratch), sbytes, None, 0), "aoc_linesearch")
         self.cur, self.jcur, self.kk, self.cur_is64, self.cur_rollout = n, jn, kk + 1, False, True
 
     def direction(self):
@@ -745,7 +760,7 @@ def backward_forward(problem, xx, uu, full_hessian, stepsize_0=1.0, f32=False):
                              _ptr(lm0), _ptr(st)), "aoc_backward")
     prm = make_params(stepsize_0=stepsize_0)
     check(lib().aoc_forward(C.byref(p), C.byref(prm), 1, _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(du),
-                            _ptr(desc), _ptr(Jn), _ptr(st), None, None), "aoc_forward")
+                            _ptr(desc), _ptr(Jn), _ptr(st), None, 0, None), "aoc_forward")
     KK = unpack_gains(Kt, B).cpu().numpy()
     return dict(KK=KK, du=unpack(du, B).cpu().numpy(),
                 descent=desc[:B].cpu().numpy(), lmbd0=unpack_vec(lm0, B).cpu().numpy(),

@@ -359,14 +359,14 @@ __device__ __forceinline__ Hess hessian(const KConst& k, const real x[6], real u
     h.h23 = l2 * f2_23 + l5 * f5_23;
     h.h25 = l0 * f0_25 + l1 * f1_25 - l2 * f2_23 + l5 * f5_25;
     h.h33 = l2 * f2_33 + l5 * f5_33;
-    h.h35 = -l2 * f2_33 - l5 * f5_33;
+    h.h35 = -h.h33;   // = -l2 * f2_33 - l5 * f5_33, which rounds to exactly that (aircraft_simplified.py:347)
     h.h55 = l0 * f0_55 + l1 * f1_55 + l2 * f2_55 + l5 * f5_55;
     // fux (:375-379)
     const real g2_03 = -k.dtm * s.sa;
     const real g5_02 = -dtmV2 * s.sa, g5_03 = dtmV * s.ca;
     h.s02 = l5 * g5_02;
     h.s03 = l2 * g2_03 + l5 * g5_03;
-    h.s05 = -l2 * g2_03 - l5 * g5_03;
+    h.s05 = -h.s03;   // = -l2 * g2_03 - l5 * g5_03 likewise (:379)
     return h;
 }
 
@@ -407,20 +407,23 @@ __host__ __device__ constexpr int sidx(int i, int j) { return i * 6 - (i * (i - 
 //                            the Riccati update itself always uses the unregularised M — Q3)
 // P is carried as a symmetric matrix (the reference's P is symmetric to rounding, |P-P^T|<=7e-11).
 // Inputs: P,p at t+1; Q (sym upper, incl. Hessian terms), S row 0 entries, q/2, r/2.  Outputs: P,p
-// at t (in place), Kt[14] = {sigma0, K0[0..5], sigma1, K1[0..5]} and flags.
+// at t (in place), the seven columns of K~_t through emit(c, K~[0][c], K~[1][c]) and flags.
 // ---------------------------------------------------------------------------------------------
 struct StageFlags { bool singular, regularised; };
 
 // Columns COLS (bit j: column j of P_t and of the feedback gains K) of one stage, and with AFFINE the affine terms
-// (sigma = Kt[0], Kt[7], and p_t in place).  P is read only; Pn receives the entries (i,j), i <= j, of the columns in
-// COLS.  lqr_stage = all six columns + affine terms.  The four-wavefront backward pass of small batches
+// (sigma, and p_t in place).  P is read only; Pn receives the entries (i,j), i <= j, of the columns in COLS; every
+// column of K~ this part owns is handed to emit(c, K~[0][c], K~[1][c]) — c = 0 the feed-forward sigma, c = 1 + j the
+// feedback column j — the moment it exists, so that a caller which stores it at once never holds the gains of a stage
+// in registers (14 doubles, which the full-Hessian backward kernel does not have to spare).
+// lqr_stage = all six columns + affine terms.  The four-wavefront backward pass of small batches
 // (k_backward4) gives three wavefronts the columns {0,1,2}, {3,4} and {5} + affine: every entry is computed by the
 // expressions below whichever wavefront owns it, so the split changes no rounding.  A column j needs the rows
 // G[:,i] = (B^T P A + S)[:,i] of all i <= j (three entries of column i of P A each), the affine terms need all six.
-template <int COLS, bool AFFINE>
+template <int COLS, bool AFFINE, typename Emit>
 __device__ __forceinline__ StageFlags lqr_stage_part(const KConst& k, const Lin& l, const real P[21], real p[6],
                                                      const real Qs[21], real s02, real s03, real s05,
-                                                     const real hq[6], const real hr[2], real Kt[14], real Pn[21]) {
+                                                     const real hq[6], const real hr[2], real Pn[21], Emit emit) {
     constexpr int JMAX = AFFINE ? 5 : (COLS >= 32 ? 5 : COLS >= 16 ? 4 : COLS >= 8 ? 3 : COLS >= 4 ? 2 : COLS >= 2 ? 1 : 0);
     // M = R + B^T P B  (2x2, symmetric), from the six entries of P that B touches
     const real P22 = P[sidx(2, 2)], P24 = P[sidx(2, 4)], P25 = P[sidx(2, 5)], P44 = P[sidx(4, 4)],
@@ -439,13 +442,33 @@ __device__ __forceinline__ StageFlags lqr_stage_part(const KConst& k, const Lin&
     // M positive definite <=> tr > 0 and det > 0 (equivalent to all(eigvals(M) > 0), optcon.py:745)
     const bool pd = (M00 + M11 > R(0.0)) && (det > R(0.0));
     fl.regularised = !pd;
-    // affine column: h = B^T p + r/2, M^-1 h
-    real h0 = R(0.0), h1 = R(0.0), mh0 = R(0.0), mh1 = R(0.0);
+    // The gains are K~ = -Mreg^-1 [h, G] with Mreg = M, or M + 0.5 I where M is not positive definite (optcon.py:745-751),
+    // while the Riccati update below always uses the unregularised M (Q3).  n = -Mreg^-1 is settled HERE, before the
+    // column loop (a short, rarely taken branch while little is alive), so that the loop is one straight run of code that
+    // can hand out each column of K~ as it goes: with the regularised gains patched in a branch AFTER the loop the
+    // compiler kept M^-1 G, its negated copy and G alive side by side across that branch.
+    real n00 = -i00, n01 = -i01, n11 = -i11;
+    if (!pd) {
+        const real r00 = M00 + R(0.5), r11 = M11 + R(0.5);
+        const real rdet = r00 * r11 - M01 * M01;
+        if (rdet == R(0.0)) fl.singular = true;
+        const real ird = rcp_fast(rdet);
+        const real j00 = r11 * ird, j01 = -M01 * ird, j11 = r00 * ird;
+        n00 = -j00; n01 = -j01; n11 = -j11;
+    }
+    // affine column: h = B^T p + r/2, M^-1 h; and the part of p_t = q/2 + A^T p - G^T (M^-1 h) that does not wait for
+    // G: tq = q/2 + A^T p, after which neither p nor q/2 is needed (the subtraction at the end completes the same
+    // expression: same roundings)
+    real mh0 = R(0.0), mh1 = R(0.0), tq[6];
     if (AFFINE) {
-        h0 = l.b20 * p[2] + l.b50 * p[5] + hr[0];
-        h1 = k.b41 * p[4] + hr[1];
+        const real h0 = l.b20 * p[2] + l.b50 * p[5] + hr[0];
+        const real h1 = k.b41 * p[4] + hr[1];
         mh0 = i00 * h0 + i01 * h1; mh1 = i01 * h0 + i11 * h1;
-        Kt[0] = -mh0; Kt[7] = -mh1;
+        emit(0, n00 * h0 + n01 * h1, n01 * h0 + n11 * h1);
+        real ap[6];
+        At_vec(k, l, p, ap);
+#pragma unroll
+        for (int i = 0; i < 6; i++) tq[i] = hq[i] + ap[i];
     }
     // Column by column: W[:,j] = (P A)[:,j], G[:,j] = (B^T W)[:,j] + S[:,j], M^-1 G[:,j],
     // z = (A^T W)[:,j], P_t[i,j] = Q[i,j] + z[i] - G[:,i]^T M^-1 G[:,j] for i <= j.  Only one column of W
@@ -475,8 +498,8 @@ __device__ __forceinline__ StageFlags lqr_stage_part(const KConst& k, const Lin&
         if (j == 5) g0 += s05;
         G0[j] = g0; G1[j] = g1;
         if (!own) continue;
+        emit(1 + j, n00 * g0 + n01 * g1, n01 * g0 + n11 * g1);
         const real mg0 = i00 * g0 + i01 * g1, mg1 = i01 * g0 + i11 * g1;
-        Kt[1 + j] = -mg0; Kt[8 + j] = -mg1;
         const real z[6] = {w[0], w[1],
                              l.a02 * w[0] + l.a12 * w[1] + l.a22 * w[2] + l.a52 * w[5],
                              l.a23 * w[2] + w[3] + l.a53 * w[5],
@@ -485,34 +508,19 @@ __device__ __forceinline__ StageFlags lqr_stage_part(const KConst& k, const Lin&
 #pragma unroll
         for (int i = 0; i <= j; i++) Pn[sidx(i, j)] = Qs[sidx(i, j)] + z[i] - (G0[i] * mg0 + G1[i] * mg1);
     }
-    if (!pd) {  // gains from the regularised M + 0.5 I (optcon.py:745-751); the Riccati update above keeps M (Q3)
-        const real r00 = M00 + R(0.5), r11 = M11 + R(0.5);
-        const real rdet = r00 * r11 - M01 * M01;
-        if (rdet == R(0.0)) fl.singular = true;
-        const real ird = rcp_fast(rdet);
-        const real j00 = r11 * ird, j01 = -M01 * ird, j11 = r00 * ird;
-        if (AFFINE) { Kt[0] = -(j00 * h0 + j01 * h1); Kt[7] = -(j01 * h0 + j11 * h1); }
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            if (!((COLS >> j) & 1)) continue;
-            Kt[1 + j] = -(j00 * G0[j] + j01 * G1[j]);
-            Kt[8 + j] = -(j01 * G0[j] + j11 * G1[j]);
-        }
-    }
     if (AFFINE) {  // p_t = q/2 + A^T p - G^T (M^-1 h)
-        real ap[6];
-        At_vec(k, l, p, ap);
 #pragma unroll
-        for (int i = 0; i < 6; i++) p[i] = hq[i] + ap[i] - (G0[i] * mh0 + G1[i] * mh1);
+        for (int i = 0; i < 6; i++) p[i] = tq[i] - (G0[i] * mh0 + G1[i] * mh1);
     }
     return fl;
 }
 
+template <typename Emit>
 __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, real P[21], real p[6],
                                                 const real Qs[21], real s02, real s03, real s05,
-                                                const real hq[6], const real hr[2], real Kt[14]) {
+                                                const real hq[6], const real hr[2], Emit emit) {
     real Pn[21];
-    const StageFlags fl = lqr_stage_part<63, true>(k, l, P, p, Qs, s02, s03, s05, hq, hr, Kt, Pn);
+    const StageFlags fl = lqr_stage_part<63, true>(k, l, P, p, Qs, s02, s03, s05, hq, hr, Pn, emit);
 #pragma unroll
     for (int e = 0; e < 21; e++) P[e] = Pn[e];
     return fl;

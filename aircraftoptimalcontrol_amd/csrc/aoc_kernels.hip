@@ -285,29 +285,33 @@ int aoc_gradient(const aoc_problem* p, const void* x, const double* u, const dou
 }
 int aoc_forward(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const void* x, const double* u,
                 const double* x0, const double* Kt, double* du, double* descent, double* J_trial, int32_t* status,
-                void* cand, const int32_t* ntrials_hint) {
-    return aoc64::api_forward(p, prm, n_spec, x, u, x0, Kt, du, descent, J_trial, status, cand, ntrials_hint);
+                void* cand, size_t cand_bytes, const int32_t* ntrials_hint) {
+    return aoc64::api_forward(p, prm, n_spec, x, u, x0, Kt, du, descent, J_trial, status, cand, cand_bytes, ntrials_hint);
 }
 size_t aoc_candidate_bytes(int32_t B, int32_t T, int32_t n_spec) {
     return B >= 1 && T >= 1 && n_spec >= 1 ? aoc64::cand_bytes(B, T, n_spec) : 0;
 }
+int32_t aoc_default_ncand(int32_t B, int32_t n_spec, int32_t armijo_maxiters) {
+    return B >= 1 && n_spec >= 1 && tuning().store_candidates ? aoc64::cand_count(B, n_spec, armijo_maxiters) : 0;
+}
 int aoc_linesearch(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const double* u, const double* x0,
                    const double* du, const double* J_cur, const double* descent, const double* J_trial, void* x_new,
                    double* u_new, double* J_new, double* stepsize, int32_t* ntrials, int32_t* status, void* scratch,
-                   const void* cand) {
+                   size_t scratch_bytes, const void* cand, size_t cand_bytes) {
     return aoc64::api_linesearch(p, prm, n_spec, u, x0, du, J_cur, descent, J_trial, x_new, u_new, J_new, stepsize,
-                                 ntrials, status, scratch, aoc64::LsFrozen{nullptr, nullptr}, cand);
+                                 ntrials, status, scratch, scratch_bytes, aoc64::LsFrozen{nullptr, nullptr}, cand, cand_bytes);
 }
 int aoc_linesearch_search(const aoc_problem* p, const aoc_params* prm, int32_t n_spec, const double* u, const double* x0,
                           const double* du, const double* J_cur, const double* descent, const double* J_trial,
-                          double* stepsize, int32_t* ntrials, void* scratch) {
-    return aoc64::api_ls_search(p, prm, n_spec, u, x0, du, J_cur, descent, J_trial, stepsize, ntrials, scratch);
+                          double* stepsize, int32_t* ntrials, void* scratch, size_t scratch_bytes) {
+    return aoc64::api_ls_search(p, prm, n_spec, u, x0, du, J_cur, descent, J_trial, stepsize, ntrials, scratch, scratch_bytes);
 }
 int aoc_linesearch_update(const aoc_problem* p, const aoc_params* prm, const double* u, const double* x0, const double* du,
                           void* x_new, double* u_new, double* J_new, double* stepsize, int32_t* ntrials, int32_t* status,
-                          void* scratch, int32_t n_spec, const double* J_trial, const void* cand) {
-    return aoc64::api_ls_update(p, prm, u, x0, du, x_new, u_new, J_new, stepsize, ntrials, status, scratch, n_spec, J_trial,
-                                cand);
+                          void* scratch, size_t scratch_bytes, int32_t n_spec, const double* J_trial, const void* cand,
+                          size_t cand_bytes) {
+    return aoc64::api_ls_update(p, prm, u, x0, du, x_new, u_new, J_new, stepsize, ntrials, status, scratch, scratch_bytes,
+                                n_spec, J_trial, cand, cand_bytes);
 }
 int aoc_lqr_tracking(const aoc_problem* p, const void* x_opt, const double* u_opt, const double* x_opt0,
                      const double* x0_reg, double* Kgain, void* x_reg, double* u_reg, int32_t* status) {

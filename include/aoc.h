@@ -117,7 +117,10 @@ typedef struct aoc_params {
 /* Scheduling knobs.  They select kernel variants and launch shapes only — results never depend on them
  * (tests/test_gpu_parity.py checks bit-identity across settings).  The defaults are read ONCE per process, at
  * the first call that needs them, from the environment variables named below; aoc_set_tuning() replaces them
- * (test hook / tuning tools), aoc_set_tuning(NULL) restores the defaults. */
+ * (test hook / tuning tools), aoc_set_tuning(NULL) restores the defaults.  The settings are one plain process-wide
+ * struct: aoc_set_tuning() must not run concurrently with any other call of this library.  (It MAY run between
+ * aoc_linesearch_search and aoc_linesearch_update: the search records the scheme it used in `scratch`, and the update
+ * resolves by that record, not by the settings of the moment.) */
 typedef struct aoc_tuning {
     int32_t nspec;          /* AOC_NSPEC        Armijo candidates riding along in the forward pass; 0 = by batch size */
     int32_t split_tiles;    /* AOC_SPLIT_TILES  several wavefronts per tile in forward/final/rollout/gains up to this many tiles (512) */
@@ -222,16 +225,20 @@ int aoc_gradient(const aoc_problem *prob, const void *x, const double *u, const 
  * aoc_linesearch.
  * Outputs: du (tiled C=2), descent[ntiles*64], J_trial[n_spec][ntiles*64].
  * cand (may be NULL; used when n_spec > 3 or the batch runs its passes on several wavefronts per tile): device memory of
- * aoc_candidate_bytes(B, T, n_spec) bytes in which every trial keeps the trajectory it rolls out (x' as float32, u',
+ * cand_bytes >= aoc_candidate_bytes(B, T, n_spec) bytes (checked: a smaller region is AOC_EINVAL, not a memory fault) in
+ * which every trial keeps the trajectory it rolls out (x' as float32, u',
  * flags); handed to aoc_linesearch / aoc_linesearch_update together with n_spec and J_trial, the update of a tile whose
  * trajectories all accepted one of these candidates is a copy, parallel over the horizon, instead of one more serial
  * rollout — the same values either way.  ntrials_hint (may be NULL): the trial counts of the previous iteration (the
  * `ntrials` array aoc_linesearch filled; zeros = none): a tile then stores only as many candidates as its trajectories
- * needed last time plus two, and the update falls back to the rollout for a tile that needed more. */
+ * needed last time plus two, and the update falls back to the rollout for a tile that needed more.
+ * aoc_default_ncand(B, n_spec, armijo_maxiters): the number of candidates aoc_newton_iterate keeps for such a batch
+ * (n_spec, or 0 = none: the batch is too large, or not every candidate rides along). */
 size_t aoc_candidate_bytes(int32_t B, int32_t T, int32_t n_spec);
+int32_t aoc_default_ncand(int32_t B, int32_t n_spec, int32_t armijo_maxiters);
 int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const void *x, const double *u,
                 const double *x0, const double *Kt, double *du, double *descent, double *J_trial,
-                int32_t *status, void *cand, const int32_t *ntrials_hint);
+                int32_t *status, void *cand, size_t cand_bytes, const int32_t *ntrials_hint);
 
 /* Armijo back-tracking (optcon.py:243-273) and the final update (optcon.py:488-491).
  * Trial ii uses alpha_ii = stepsize_0*beta^ii and is accepted iff J'(alpha_ii) <= J_cur +
@@ -239,13 +246,15 @@ int aoc_forward(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, 
  * J_trial may be NULL).
  * Trajectories still rejected search on: small batches in rounds over a compacted list, several
  * candidate steps of each at once when few remain; large batches through a work list of (trajectory,
- * up to four consecutive candidates) items, a lane carrying the rollouts of its candidates side by side
- * from one read of (u, du).  The accepted index is the first one that passes, as in the reference's
+ * candidate step) items, one cost-only rollout per item and lane, the items of one trajectory neighbours on
+ * the list (aoc_tuning.ls_cpl = 2 or 4 lets an item carry that many consecutive candidates from one read of
+ * (u, du): measured slower, not the default).  The accepted index is the first one that passes, as in the reference's
  * sequential loop, whatever the schedule (aoc_tuning).  On exhaustion the untested
  * stepsize_0*beta^armijo_maxiters is used (Q5).  Finally EVERY trajectory is rolled out with its
  * step into x_new/u_new and J_new.  stepsize[b], ntrials[b] report the result.
- * armijo_maxiters <= 63.  scratch: device memory of aoc_linesearch_scratch_bytes(B, T) bytes.  cand: NULL, or the
- * candidate store aoc_forward filled for the same n_spec (see there). */
+ * armijo_maxiters <= 63.  scratch: device memory of scratch_bytes >= aoc_linesearch_scratch_bytes(B, T) bytes.  cand: NULL,
+ * or the candidate store aoc_forward filled for the same n_spec (see there), of cand_bytes >= aoc_candidate_bytes(B, T,
+ * n_spec) bytes.  Both sizes are checked: too small a region is AOC_EINVAL, not a memory fault. */
 size_t aoc_linesearch_scratch_bytes(int32_t B, int32_t T);
 /* Largest n_spec aoc_forward / aoc_linesearch take, and the n_spec aoc_newton_iterate uses for a batch of B
  * trajectories: 2 in general, armijo_maxiters for batches small enough to give every candidate step its own
@@ -255,7 +264,8 @@ int32_t aoc_default_nspec(int32_t B, int32_t armijo_maxiters);
 int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const double *u,
                    const double *x0, const double *du, const double *J_cur, const double *descent,
                    const double *J_trial, void *x_new, double *u_new, double *J_new, double *stepsize,
-                   int32_t *ntrials, int32_t *status, void *scratch, const void *cand);
+                   int32_t *ntrials, int32_t *status, void *scratch, size_t scratch_bytes, const void *cand,
+                   size_t cand_bytes);
 
 /* The two halves of aoc_linesearch, which is exactly _search followed by _update on the same arguments:
  *   aoc_linesearch_search = armijo_stepsize for every trajectory (optcon.py:204-327): stepsize[b], ntrials[b]; the
@@ -266,11 +276,12 @@ int aoc_linesearch(const aoc_problem *prob, const aoc_params *prm, int32_t n_spe
  * (Separate entry points so that a caller can time or overlap the latency-bound search and the streaming update.) */
 int aoc_linesearch_search(const aoc_problem *prob, const aoc_params *prm, int32_t n_spec, const double *u,
                           const double *x0, const double *du, const double *J_cur, const double *descent,
-                          const double *J_trial, double *stepsize, int32_t *ntrials, void *scratch);
+                          const double *J_trial, double *stepsize, int32_t *ntrials, void *scratch,
+                          size_t scratch_bytes);
 int aoc_linesearch_update(const aoc_problem *prob, const aoc_params *prm, const double *u, const double *x0,
                           const double *du, void *x_new, double *u_new, double *J_new, double *stepsize,
-                          int32_t *ntrials, int32_t *status, void *scratch, int32_t n_spec, const double *J_trial,
-                          const void *cand);
+                          int32_t *ntrials, int32_t *status, void *scratch, size_t scratch_bytes, int32_t n_spec,
+                          const double *J_trial, const void *cand, size_t cand_bytes);
 
 /* lqr_tracking.lqr_tracking (lqr_tracking.py:245-283): linearise about (x_opt,u_opt), non-augmented
  * Riccati/gain recursion with the constant weights QQt,RRt,QQT of `prob` and S = 0
@@ -295,9 +306,12 @@ int aoc_ltv_lqr(int32_t nb, int32_t T, int32_t augmented, const double *A, const
                 int32_t *nreg, int32_t *nsing, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Iteration level.  Workspace: caller-allocated device memory of aoc_workspace_bytes(B,T) bytes; its size is passed
- * along (`workspace_bytes`) and checked: too small a workspace is an AOC_EINVAL, not a memory fault.  (A workspace sized
- * for B trajectories also serves any smaller batch.)
+ * Iteration level.  Workspace: caller-allocated device memory of aoc_workspace_bytes(B,T) bytes — what a batch of
+ * exactly B trajectories needs (K~, du, trial costs, line-search scratch, and the candidate store where a batch of that
+ * size keeps one) — its size is passed along (`workspace_bytes`) and checked: too small a workspace is an AOC_EINVAL,
+ * not a memory fault; one without room for the candidate store makes the update roll out instead of copy (same
+ * results).  aoc_solve_workspace_bytes() includes the largest candidate store of any batch up to B, because
+ * aoc_newton_solve runs its re-packed, smaller generations in the workspace of the first.
  * --------------------------------------------------------------------------------------------- */
 size_t aoc_workspace_bytes(int32_t B, int32_t T);
 

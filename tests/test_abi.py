@@ -33,14 +33,21 @@ def test_geometry_helpers_and_errors():
     assert lib.aoc_tiled_elems(100, 500, 6) == 2 * 500 * 6 * 64
     up = lambda v: (v + 255) // 256 * 256
     base = lambda B: B * 500 * 16 * 8 + lib.aoc_spec_max() * B * 8 + up(lib.aoc_linesearch_scratch_bytes(B, 500))
-    # small batches with at most one forward workgroup per CU keep the candidate trajectories; the region is sized for the
-    # largest need of any batch up to B, because aoc_newton_solve runs its smaller generations in the same workspace
+    # a batch small enough to give every Armijo candidate a wavefront of its own (tiles x groups of three <= 256) keeps the
+    # candidate trajectories: aoc_workspace_bytes(B) holds the largest store a batch of exactly B can ask for ...
     assert lib.aoc_workspace_bytes(64, 500) == base(64) + lib.aoc_candidate_bytes(64, 500, lib.aoc_spec_max())
     assert lib.aoc_candidate_bytes(64, 500, 10) == 10 * (64 * 500 * 48 + 64 * 4) + 16   # records, flags, stored count per tile
-    sizes = [lib.aoc_workspace_bytes(B, 500) for B in (1, 64, 65, 1000, 4096, 6000, 8192, 8193, 40000, 131072)]
-    assert sizes == sorted(sizes)
-    assert lib.aoc_workspace_bytes(131072, 500) - base(131072) == max(lib.aoc_workspace_bytes(64 * t, 500) - base(64 * t) for t in range(1, 257))
-    assert lib.aoc_workspace_bytes(131072, 500) - base(131072) < 1.3e9
+    for B, m in ((4096, 12), (8192, 6), (5440, 9), (4096, 10), (3264, 15)):    # (tiles, candidates) at the edge of the rule
+        assert lib.aoc_default_ncand(B, m, m) == m, (B, m)
+        assert lib.aoc_workspace_bytes(B, 500) >= base(B) + lib.aoc_candidate_bytes(B, 500, m), (B, m)
+    assert lib.aoc_default_ncand(8192 + 64, 6, 6) == 0 and lib.aoc_default_ncand(4096, 9, 10) == 0
+    # ... a large batch none (three solvers of 131 072 trajectories used to carry 3.5 GB they never touched) ...
+    assert lib.aoc_workspace_bytes(131072, 500) == base(131072)
+    # ... and aoc_solve_workspace_bytes the largest store of ANY batch up to B: aoc_newton_solve runs its re-packed,
+    # smaller generations in the workspace of the first (768 stored (tile, candidate) pairs at most)
+    extra = max(lib.aoc_workspace_bytes(64 * t, 500) - base(64 * t) for t in range(1, 257))
+    assert lib.aoc_solve_workspace_bytes(131072, 500) - lib.aoc_solve_workspace_bytes(131072, 500) % 256 >= base(131072) + extra - 256
+    assert 768 * (500 * 64 * 48 + 256) <= extra < 768 * (500 * 64 * 48 + 256) + 4096
     assert b"gfx950" in lib.aoc_version()
     assert lib.aoc_strerror(-1) == b"invalid argument"
     # struct layout must match the header: 9 doubles + 76 doubles + 8 int32 + 2 pointers
@@ -115,8 +122,9 @@ def test_argument_errors_carry_a_reason():
 
 
 def test_too_small_a_workspace_is_an_error_not_a_fault():
-    """aoc_newton_iterate / aoc_newton_solve / aoc_mpc_step are told the size of their workspace and refuse one that is
-    too small before anything is launched."""
+    """aoc_newton_iterate / aoc_newton_solve / aoc_mpc_step are told the size of their workspace, aoc_forward /
+    aoc_linesearch* the sizes of their scratch and candidate regions, and refuse one that is too small before anything
+    is launched."""
     lib = _lib.lib()
     p = _lib.Problem()
     p.B, p.T, p.ref = 4096, 500, 1
@@ -126,3 +134,17 @@ def test_too_small_a_workspace_is_an_error_not_a_fault():
     assert rc == -1 and b"workspace" in lib.aoc_last_hip_error()
     rc = lib.aoc_newton_solve(C.byref(p), C.byref(prm), 1, 1, 1, 1, 1000, 4, 1, 1, 1, 1, 1, None, None, None, None, None)
     assert rc == -1 and b"workspace" in lib.aoc_last_hip_error()
+    # pass level: line-search scratch and candidate store
+    sb, cb = lib.aoc_linesearch_scratch_bytes(4096, 500), lib.aoc_candidate_bytes(4096, 500, 10)
+    assert lib.aoc_linesearch_search(C.byref(p), C.byref(prm), 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, sb - 1) == -1
+    assert b"scratch" in lib.aoc_last_hip_error()
+    assert lib.aoc_linesearch_update(C.byref(p), C.byref(prm), 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, sb - 1, 0, None, None, 0) == -1
+    assert b"scratch" in lib.aoc_last_hip_error()
+    assert lib.aoc_linesearch_update(C.byref(p), C.byref(prm), 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, sb, 10, 1, 1, cb - 1) == -1
+    assert b"candidate" in lib.aoc_last_hip_error()
+    assert lib.aoc_linesearch(C.byref(p), C.byref(prm), 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 16, None, 0) == -1
+    assert b"scratch" in lib.aoc_last_hip_error()
+    assert lib.aoc_forward(C.byref(p), C.byref(prm), 10, 1, 1, 1, 1, 1, 1, 1, 1, 1, cb - 1, None) == -1
+    assert b"candidate" in lib.aoc_last_hip_error()
+    # a candidate store sized for another n_spec (the overrun of round 2) is refused too
+    assert lib.aoc_forward(C.byref(p), C.byref(prm), 10, 1, 1, 1, 1, 1, 1, 1, 1, 1, lib.aoc_candidate_bytes(4096, 500, 7), None) == -1
