@@ -287,6 +287,21 @@ class NewtonBatchSolver:
         check(lib().aoc_traj_cost(C.byref(p), _ptr(self.xb[0]), _ptr(self.ub[0]), _ptr(self.x0), _ptr(self.J[0])),
               "aoc_traj_cost")
 
+    def set_initial_from_rollout(self, x0, uu):
+        """Initial iterate = the open-loop rollout of uu (B,2,T) from x0 (B,6) (get_update with no direction,
+        optcon.py:176-200): the warm start of BASELINE configs[2] from a saved optimum, rolled out on the device."""
+        torch = _torch()
+        dev = self.problem.device
+        self.x0.copy_(pack_vec(x0, dev))
+        ut = pack(uu, dev)
+        self.x_init = self.u_init = None
+        self.cur_is64 = False
+        self.status.zero_()
+        p = self._p()
+        check(lib().aoc_rollout_cost(C.byref(p), _ptr(self.x0), _ptr(ut), None, None, _ptr(self.xb[0]), _ptr(self.ub[0]),
+                                     _ptr(self.J[0]), _ptr(self.status)), "aoc_rollout_cost")
+        self.cur, self.kk, self.jcur, self.cur_rollout = 0, 0, 0, True
+
     def iterate(self, kk=None):
         """One outer iteration (steps A-G of SURVEY 3.2) for every trajectory; asynchronous."""
         if kk is None:

@@ -14,7 +14,8 @@ from oracle import oracle as orc
 
 
 def sweep(aoc, problems, B=4096, n_it=12, dist="random", prob="step", seed=4242, log=None):
-    pr = problems.step_maneuver(1.0, 2e-3) if prob == "step" else problems.acrobatic(1.0, 2e-3)
+    # step maneuver at the bench's T = 500; the acrobatic problem at the reference's native T = 1000 (acrobatic_newton.py:72-76)
+    pr = problems.step_maneuver(1.0, 2e-3) if prob == "step" else problems.acrobatic(1.0, 1e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     op = orc.OracleProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     x0 = problems.random_x0(B, seed=seed) if dist == "random" else problems.perturbed_x0(pr, B, seed=seed)
@@ -55,6 +56,8 @@ def sweep(aoc, problems, B=4096, n_it=12, dist="random", prob="step", seed=4242,
             n_regularised=int(flagged.sum()),
             u_channel_rel_max=mx(chan, ok), u_channel_rel_max_unflagged=mx(chan, ok & ~flagged),
             u_elementwise_rel_max_unflagged=mx(elem, ok & ~flagged), u_elementwise_rel_median=float(np.median(elem[ok])) if ok.any() else 0.0,
+            u_elementwise_rel_p999=float(np.percentile(elem[ok], 99.9)) if ok.any() else 0.0,
+            u_channel_rel_median=float(np.median(chan[ok])) if ok.any() else 0.0,
             n_elementwise_over_1e8=int((elem[ok & ~flagged] > 1e-8).sum()),
             x_bit_identical=int((x_same & ok).sum())))
         if log:

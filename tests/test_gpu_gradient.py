@@ -95,3 +95,37 @@ def test_dropin_gradient_method_runs_like_the_reference_would():
     bp = aoc.BatchProblem(pg["QQt"], pg["RRt"], pg["QQT"], pg["xx_ref"], pg["uu_ref"], float(pg["dt"]))
     us = uu_star.copy(); us[:, -1] = 0.0
     assert aoc.traj_cost(bp, xx_star[None], us[None])[0] < cost[-1]
+
+
+def test_gradient_solve_stays_a_gradient_solve_when_it_compacts():
+    """solve() re-packs the still-iterating trajectories into a smaller solver once fewer than half
+    are active; that solver must be of the caller's class — a compacted GradientBatchSolver used to continue with
+    Newton iterations.  A stopping threshold chosen so that ~60 % stop after two iterations makes the re-packing happen
+    (B > compact_min); results with and without it must be identical."""
+    from aircraftoptimalcontrol_amd import batch as aoc, problems
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 2200
+    x0 = problems.perturbed_x0(pr, B, seed=12)
+    probe = aoc.GradientBatchSolver(bp, B, aoc.make_params(stepsize_0=1e-1, armijo_maxiters=20))
+    probe.set_initial_from_x0(x0)
+    probe.iterate(0); probe.iterate(1)
+    thr = float(np.percentile(probe.scalars()["descent"], 40))      # slopes are negative: 60 % lie above
+    prm = aoc.make_params(max_iters=7, stepsize_0=1e-1, armijo_maxiters=20, term_cond=thr)
+    res = []
+    for compact in (True, False):
+        s = aoc.GradientBatchSolver(bp, B, prm)
+        s.set_initial_from_x0(x0)
+        seen = []
+        r = s.solve(compact=compact, callback=lambda kk, sc: seen.append(len(sc["cost"])))
+        res.append((r, seen))
+    (a, sa), (b, sb) = res
+    assert min(sa) < B and min(sb) == B, (sa, sb)                    # the first run really re-packed
+    assert a["converged"].sum() > 0.3 * B and len(set(sa)) >= 2     # some stopped early, the rest went on in a smaller batch
+    for key in ("xx_star", "uu_star", "iters", "converged", "status"):
+        assert np.array_equal(a[key], b[key], equal_nan=True), key
+    for key in a["history"]:
+        assert np.array_equal(a["history"][key], b["history"][key], equal_nan=True), key
+    # and they are gradient iterations: every recorded slope is -sum |du|^2 < 0, after the re-packing too
+    d = a["history"]["descent"]
+    assert np.isfinite(d[:, -1]).any() and (d[np.isfinite(d)] < 0).all()

@@ -14,13 +14,13 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _bench(tmp, gpus, per_gpu, steps=3):
-    d = tmp / ("n%d" % gpus)
+def _bench(tmp, gpus, per_gpu, steps=3, extra=("--cpu-budget-s", "1.5")):
+    d = tmp / ("n%d_%d" % (gpus, per_gpu))
     d.mkdir()
     env = dict(os.environ, AOC_BENCH_ONE_DEVICE="1", AOC_BENCH_BACKEND="gloo", AOC_BENCH_DUMP=str(d))
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", str(steps),
-                        "--warmup", "1", "--batch-per-gpu", str(per_gpu), "--no-cpu-baseline"], env=env,
+                        "--warmup", "1", "--batch-per-gpu", str(per_gpu)] + list(extra), env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -43,9 +43,37 @@ def test_two_ranks_through_the_real_solver_equal_one_process(tmp_path):
     assert np.allclose(parts[0]["summary"], whole["summary"], rtol=1e-12, atol=0)
     assert parts[0]["summary"][3] == 2 * per
     assert two["steps"] == 3 and two["value"] > 0 and two["scaling"] == "weak"
+    # the N > 1 line is a full record and says what ran: the CPU baseline and the comparison with the
+    # oracle come from rank 0 after the process group is gone, the collective is named and timed by itself
+    cb = two["cpu_baseline"]
+    assert cb is not None and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and "cpu_baseline_error" not in two
+    re_ = two["rel_err_vs_oracle"]
+    assert re_["n"] >= 1 and re_["iterations"] == 3 and re_["identical_step_and_trial_history"] >= 0.99 * re_["n"]
+    assert re_["all_finite"]["u_rel_channel"]["median"] < 1e-9
+    co = two["collective"]
+    assert co["world_seen"] == 2 and co["backend"] == "gloo" and co["payload_bytes"] == 40 and co["us"] > 0
+    lo, hi = two["per_rank_ms_per_step"]
+    assert 0 < lo <= hi and abs(hi - two["ms_per_step"]) < 1e-9
+    assert one["collective"] is None and len(one["per_rank_ms_per_step"]) == 2
     out = os.path.join(ROOT, "gpurun_out", "two_rank_rehearsal.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump({"two_ranks_one_device_gloo": two, "one_process": one}, open(out, "w"), indent=1)
+
+
+def test_strong_scaling_option_splits_a_global_batch(tmp_path):
+    """--global-batch G: the same total work over N ranks ("scaling": "strong"); each rank owns G / N contiguous global
+    indices, so the shards of a 2-rank run are the halves of the 1-rank run."""
+    G = 2 * 4160
+    two, parts = _bench(tmp_path, 2, 0, steps=2, extra=("--global-batch", str(G), "--no-cpu-baseline"))
+    assert two["scaling"] == "strong" and two["config"]["global_batch"] == G and two["config"]["batch_per_gpu"] == G // 2
+    assert [int(p["first"]) for p in parts] == [0, G // 2] and parts[0]["xx"].shape[0] == G // 2
+    assert two["cpu_baseline"] is None and two["collective"]["world_seen"] == 2
+    # a global batch that does not divide is refused before anything runs
+    env = dict(os.environ, AOC_BENCH_ONE_DEVICE="1", AOC_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--global-batch", "8321"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "not a multiple" in r.stderr
 
 
 def test_two_stream_solver_equals_one_stream():

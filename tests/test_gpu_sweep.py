@@ -1,6 +1,6 @@
-"""Parity at scale as a test (round 1 ran it by hand): 4096 random-x0 + 4096 perturbed step-maneuver + 2048 perturbed
-acrobatic trajectories x 12 teacher-forced iterations = 122 880 trajectory-iterations, every one redone by the oracle
-from the GPU's own iterate.  The gates are the bounds the path really meets:
+"""Parity at scale as a test (round 1 ran it by hand): 4096 random-x0 + 4096 perturbed step-maneuver (T = 500, the bench's
+horizon) + 2048 perturbed acrobatic trajectories (T = 1000, the reference's native horizon) x 12 teacher-forced
+iterations = 122 880 trajectory-iterations, every one redone by the oracle from the GPU's own iterate.  The gates are the bounds the path really meets:
 
   Gauss-Newton iterations (kk <= 8)
     * accepted step and trial count identical for EVERY trajectory; cost of the iterate identical to the last bit
