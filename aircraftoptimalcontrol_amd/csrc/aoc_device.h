@@ -187,14 +187,18 @@ __device__ __forceinline__ void pin_consts(KConst& k) {
         if (!DIAG || i % 3 == 0) vpin(k.R[i]);
 }
 
+// one fused multiply-add in the arithmetic type (a bare __builtin_fma on floats is a DOUBLE fma between two conversions)
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // a / b for a wave-uniform b with rb = RN(1/b): q0 = RN(a rb), r = a - q0 b (exact, one fma), RN(q0 + r rb).
 // Markstein's correction: the result IS the correctly rounded quotient (b finite, not of all-ones
 // significand; a, a/b in the normal range), i.e. bit-identical to the reference's `uu[1] / J`, in three
 // instructions instead of the ~15 (one quarter-rate) of the IEEE division expansion.  a = +-inf gives NaN.
 __device__ __forceinline__ real div_by_const(real a, real b, real rb) {
     const real q0 = a * rb;
-    const real r = __builtin_fma(-q0, b, a);
-    return __builtin_fma(r, rb, q0);
+    const real r = fma_r(-q0, b, a);
+    return fma_r(r, rb, q0);
 }
 
 // 1/b to ~1 ulp for the linearisation and the 2x2 gain solve (results compared at 1e-8, not bit for bit):
@@ -206,7 +210,14 @@ __device__ __forceinline__ double rcp_fast(double b) {
     e = __builtin_fma(-b, y, 1.0);
     return __builtin_fma(y, e, y);
 }
-__device__ __forceinline__ float rcp_fast(float b) { return 1.0f / b; }
+// float32 arithmetic is not a parity path (config 3: tolerance sweep): v_rcp_f32 (1 ulp) as it is, instead of the ten
+// instructions of the IEEE division expansion
+__device__ __forceinline__ float rcp_fast(float b) { return __builtin_amdgcn_rcpf(b); }
+
+// a / b where the reference divides (aircraft_simplified.py:310, dt / (m V)): the parity path divides exactly, the
+// float32 build multiplies by the reciprocal
+__device__ __forceinline__ double div_r(double a, double b) { return a / b; }
+__device__ __forceinline__ float div_r(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
 #pragma clang fp contract(off)
 __device__ __forceinline__ void step_state(const KConst& k, const real x[6], real u0, real u1,
@@ -220,7 +231,7 @@ __device__ __forceinline__ void step_state(const KConst& k, const real x[6], rea
     xp[2] = (real)(float)(V + k.dtm * (-D - k.mg * s.sg + u0 * s.ca)); // :306
     xp[3] = (real)(float)(x[3] + k.dt * x[4]);                        // :307
     xp[4] = (real)(float)(x[4] + k.dt * div_by_const(u1, k.J, k.rJ)); // :309  u1 / J
-    xp[5] = (real)(float)(x[5] + (k.dt / (k.m * V)) * (L - k.mg * s.cg + u0 * s.sa)); // :310
+    xp[5] = (real)(float)(x[5] + div_r(k.dt, k.m * V) * (L - k.mg * s.cg + u0 * s.sa)); // :310
 }
 
 // Stage and terminal cost.  The reference evaluates l = (0.5 dx)^T (Q dx) + (0.5 du)^T (R du)

@@ -27,11 +27,13 @@ def env_rank_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend="nccl", device=None):
-    """torch.distributed over RCCL ("nccl") or gloo when WORLD_SIZE > 1; no-op for one rank.  Returns world."""
+def init_process_group(backend="nccl", device=None, force=False):
+    """torch.distributed over RCCL ("nccl") or gloo when WORLD_SIZE > 1; no-op for one rank unless `force` (a one-rank
+    group: what the one-GPU test of the RCCL branch uses).  Returns world.  An initialisation failure raises: there is
+    no fallback to another backend."""
     import torch.distributed as dist
     _, _, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -66,7 +68,7 @@ def all_reduce(vec, op="sum"):
     import torch.distributed as dist
     is_t = isinstance(vec, torch.Tensor)
     t = vec if is_t else torch.as_tensor(np.asarray(vec, dtype=np.float64))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():   # a one-rank group reduces too (identity, but through the backend)
         rop = dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX
         if t.is_cuda and dist.get_backend() != "nccl":
             h = t.cpu()

@@ -101,3 +101,40 @@ def test_two_stream_solver_equals_one_stream():
     ja, da, na = (t.cpu().numpy() for t in one.summary_tensors())
     jb, db, nb = (t.cpu().numpy() for t in two.summary_tensors())
     assert np.array_equal(ja, jb, equal_nan=True) and np.array_equal(da, db, equal_nan=True) and np.array_equal(na, nb)
+
+
+def test_rccl_branch_on_one_gpu(tmp_path):
+    """The branch the 8-GPU run takes — dist.init_process_group("nccl", device_id=...), the in-place RCCL all-reduce of a
+    DEVICE tensor, dist.barrier() under nccl — cannot run with two ranks on one GPU (RCCL refuses a duplicate device), so
+    it is exercised with a one-rank group in a child process: RCCL loads, the communicator comes up on cuda:0, the
+    summary vector goes through ncclAllReduce and comes back unchanged, the group is torn down."""
+    code = r"""
+import os, sys, socket
+sys.path.insert(0, %r)
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+from aircraftoptimalcontrol_amd import sharding
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+sharding.init_process_group("nccl", dev, force=True)
+assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+cost = torch.tensor([1.5, float("nan"), 2.5], dtype=torch.float64, device=dev)
+vec = sharding.local_summary(cost, torch.tensor([-1.0, -2.0, -3.0], dtype=torch.float64, device=dev), torch.tensor([1, 2, 3], dtype=torch.int32, device=dev))
+ref = vec.clone()
+out = sharding.reduce_summary(vec)
+torch.cuda.synchronize(dev)
+assert out.is_cuda and out.data_ptr() == vec.data_ptr()          # reduced in place on the device, by RCCL
+assert torch.equal(out, ref) and out.tolist() == [4.0, -4.0, 6.0, 3.0, 1.0]
+mx = sharding.all_reduce(torch.tensor([3.25], dtype=torch.float64, device=dev), "max")
+assert mx.item() == 3.25
+dist.barrier(); torch.cuda.synchronize(dev)
+dist.destroy_process_group()
+print("RCCL_ONE_RANK_OK")
+""" % ROOT
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -12,7 +12,7 @@ if "error:" in err:
     print(err[-3000:]); sys.exit(1)
 for b in re.split(r"remark: [^\n]*Function Name: ", err)[1:]:
     name = b.split("\n")[0].split()[0]
-    if not name.startswith("_ZN5aoc64"): continue
+    if not name.startswith(("_ZN5aoc64", "_ZN5aoc32")): continue
     dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
     if "<" not in dem: continue
     g = lambda k: int(m.group(1)) if (m := re.search(k + r": (\d+)", b)) else -1
