@@ -379,6 +379,51 @@ class NewtonBatchSolver:
         self.cur, self.jcur, self.kk, self.cur_is64, self.cur_rollout = n, jn, kk + 1, False, True
         return ev
 
+    def tune_placement(self, x0, ws_candidates=6, iterate_candidates=4, iters=4):
+        """Allocation autotuning for large batches.  Measured on MI355X (tools/placement_probe2.py): the duration of the
+        write-heavy passes depends on WHERE their output buffers were allocated — the backward pass between 1.66 and
+        2.0 ms with the K~ workspace (7.3 GB written per pass), the update pass 0.80 or 0.93 ms with the iterate buffers —
+        reproducibly per allocation, whatever the horizon; the read side does not care.  So: allocate a few candidates for
+        the workspace, then for the set of iterate buffers, time `iters` Newton iterations from x0 (B,6) pass by pass on
+        each, keep the fastest and free the rest.  Results do not depend on it (the buffers hold the same values).
+        Returns the measurements (ms per pass and candidate) or None for batches too small to stream (< 1024 tiles)."""
+        torch = _torch()
+        if self.nt < 1024 or (ws_candidates < 2 and iterate_candidates < 2):
+            return None
+        x0 = _dev_f64(x0, self.problem.device)
+
+        def score():
+            self.set_initial_from_x0(x0)
+            self.ntrials.zero_()
+            evs = [self.iterate_timed(k) for k in range(iters)]
+            torch.cuda.synchronize(self.problem.device)
+            ms = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in evs])
+            return ms[1:].mean(0)          # [backward, forward, search, update]
+
+        rep = {"passes": list(self.PASSES)}
+        score()                             # warm-up: lazily loaded code objects
+        cands = [self.ws] + [torch.empty_like(self.ws) for _ in range(max(ws_candidates, 1) - 1)]
+        sc = []
+        for c in cands:
+            self.ws = c
+            sc.append(score())
+        best = int(np.argmin([v[0] + v[1] + v[3] for v in sc]))
+        self.ws = cands[best]
+        rep["workspace"] = {"ms": [[round(float(x), 3) for x in v] for v in sc], "chosen": best}
+        del cands
+        sets = [(self.xb, self.ub)] + [([torch.zeros_like(t) for t in self.xb], [torch.zeros_like(t) for t in self.ub])
+                                         for _ in range(max(iterate_candidates, 1) - 1)]
+        sc = []
+        for xb, ub in sets:
+            self.xb, self.ub = xb, ub
+            sc.append(score())
+        best = int(np.argmin([v[0] + v[1] + v[3] for v in sc]))
+        self.xb, self.ub = sets[best]
+        rep["iterates"] = {"ms": [[round(float(x), 3) for x in v] for v in sc], "chosen": best}
+        del sets
+        torch.cuda.empty_cache()
+        return rep
+
     # -- results ---------------------------------------------------------------------------------
     def direction(self):
         """du (B,2,T) of the last iteration (it stays in the workspace until the next one)."""
@@ -674,6 +719,11 @@ class TwoStreamNewtonSolver:
         self._on(lambda i, sv: sv.set_initial_from_x0(cut[i], kp, kt))
         self.kk = 0
         self.join()
+
+    def tune_placement(self, x0, **kw):
+        """NewtonBatchSolver.tune_placement for each half (one after the other, on the caller's stream)."""
+        x0 = _dev_f64(x0, self.problem.device)
+        return [sv.tune_placement(c, **kw) for sv, c in zip(self.parts, (x0[:self.Ba], x0[self.Ba:]))]
 
     def iterate(self, kk=None):
         """One outer iteration of every trajectory: enqueued on the two streams, no join."""

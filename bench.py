@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the small configs reported beside the headline")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream; the timed region itself carries the per-pass HIP events")
+    ap.add_argument("--placement-tuning", action="store_true",
+                    help="allocation autotuning before the run (batch.NewtonBatchSolver.tune_placement); off by default: it buys "
+                         "1-2 %% on the two-stream headline (DESIGN.md section 4, 'placement')")
     return ap.parse_args()
 
 
@@ -394,6 +397,13 @@ def run(a):
         every = sharding.all_reduce(every, "sum").cpu().numpy()        # each rank's own clock
         return float(every.max()), every, summ, evs
 
+    # optional allocation autotuning, before anything is timed: the write-heavy passes run 10-20 % faster or slower depending
+    # on where their output buffers were allocated (batch.NewtonBatchSolver.tune_placement; measurements in `placement_tuning`)
+    placement = None
+    if a.placement_tuning:
+        placement = {"one_stream_solver": s.tune_placement(x0d)}
+        if overlap:
+            placement["two_stream_halves"] = s2.tune_placement(x0d)
     # warmup: W iterations from the initial guess (and one summary, so that no lazily loaded code object is first
     # touched inside the timed region), then reset: the timed region is exactly iterations 0..K-1 of the solve
     for sv in ([s2, s] if overlap else [s]):
@@ -491,6 +501,7 @@ def run(a):
         # whole iteration, per GPU: SURVEY 8d's 496 B per trajectory-stage over the wall time of a step
         "iteration_hbm_frac_per_gpu": ITERATION_BYTES * units * K / el / 1e9 / HBM_PEAK_GBS,
         "per_rank_ms_per_step": [float(every.min() / K * 1e3), float(every.max() / K * 1e3)],
+        "placement_tuning": placement,
         "collective": coll,
         "last_iter_mean_armijo_trials": float(summ[2].item() / summ[3].item()),
         "final_mean_cost_finite": float(summ[0].item() / max(fin_b, 1)),
