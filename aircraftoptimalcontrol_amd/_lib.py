@@ -59,7 +59,7 @@ class Params(C.Structure):
 
 class Tuning(C.Structure):
     """aoc_tuning (include/aoc.h): scheduling knobs; results never depend on them."""
-    _fields_ = [(n, C.c_int32) for n in ("nspec", "split_tiles", "split_bw_tiles", "reserved0", "ls_wcap", "ls_kgrow",
+    _fields_ = [(n, C.c_int32) for n in ("nspec", "split_tiles", "split_bw_tiles", "fw_lin", "ls_wcap", "ls_kgrow",
                                          "trial_split", "solve_norepack", "ls_worklist", "ls_cpl", "ls_depth_min",
                                          "fw_recompute", "store_candidates", "bw4_tiles")] + \
                [("reserved", C.c_int32 * 2)]

@@ -103,6 +103,7 @@ static void tuning_defaults(aoc_tuning* t) {
     t->nspec = env("AOC_NSPEC", 0);
     t->split_tiles = env("AOC_SPLIT_TILES", 512);
     t->split_bw_tiles = env("AOC_SPLIT_BW_TILES", 512);
+    t->fw_lin = env("AOC_FW_LIN", -1);
     t->ls_wcap = env("AOC_LS_WCAP", 0);
     t->ls_kgrow = env("AOC_LS_KGROW", 0);
     t->trial_split = env("AOC_TRIAL_SPLIT", 1);

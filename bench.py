@@ -92,11 +92,13 @@ def kernel_names(ntiles, full):
     fl = "true, false, true, true" if full else "true, false, false, false"   # <diagonal weights, shared reference, full Hessian, costate>
     wl = t.ls_worklist > 0 or (t.ls_worklist < 0 and ntiles > t.split_tiles)
     small = ntiles <= t.split_tiles
+    nspec = _lib.lib().aoc_default_nspec(ntiles * 64, 10)
+    lin = t.fw_lin > 0 or (t.fw_lin < 0 and nspec <= 2)
     return {
         "backward": "k_backward4<true, false, false, false, float>" if (not full and ntiles <= min(t.bw4_tiles, t.split_bw_tiles)) else
                     ("k_backward2<%s, float>" if ntiles <= t.split_bw_tiles else "k_backward<%s, float>") % fl,
         # <diagonal, shared reference, 2 speculated trials, states re-computed (the iterates of the run are rollouts), float32 states>
-        "forward": "k_forward_split<true, false, float>" if small else
+        "forward": ("k_forward_lin<true, false, float>" if lin else "k_forward_split<true, false, float>") if small else
                    "k_forward<true, false, 2, %s, float>" % ("true" if t.fw_recompute else "false"),
         "linesearch_update": "k_ls_final_split<true, false, float>" if small else "k_ls_final<true, false, float>",
         "linesearch_search": ("phase: k_ls_init_wl, k_ls_plan_wl, k_ls_trial_wl<true, false, %d, pinned|plain> x2, k_ls_replan" % max(t.ls_cpl, 1)) if wl

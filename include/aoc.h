@@ -125,7 +125,9 @@ typedef struct aoc_tuning {
     int32_t nspec;          /* AOC_NSPEC        Armijo candidates riding along in the forward pass; 0 = by batch size */
     int32_t split_tiles;    /* AOC_SPLIT_TILES  several wavefronts per tile in forward/final/rollout/gains up to this many tiles (512) */
     int32_t split_bw_tiles; /* AOC_SPLIT_BW_TILES  ... in the backward pass (512) */
-    int32_t reserved0;
+    int32_t fw_lin;         /* AOC_FW_LIN       small-batch forward pass with the nominal-point work (cost gradients, sin/cos, Jacobians) on a
+                               wavefront of its own beside the LQR wavefront (k_forward_lin): 1 = always, 0 = never, -1 = where it
+                               wins: at most two candidates riding along (-1) */
     int32_t ls_wcap;        /* AOC_LS_WCAP      wavefronts a trial round may occupy (0 = 1024) / the first work list may take with every remaining candidate (0 = 2048) */
     int32_t ls_kgrow;       /* AOC_LS_KGROW     round-based line search: growth of the candidates per round; 0 = by batch size */
     int32_t trial_split;    /* AOC_TRIAL_SPLIT  two-wavefront trial kernels for latency-bound rounds (1) */

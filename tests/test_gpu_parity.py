@@ -639,6 +639,50 @@ def test_split_kernels_equal_single_wavefront_kernels(aoc, tuned):
             assert np.array_equal(a[key], b[key], equal_nan=True), key
 
 
+def test_forward_pass_with_a_linearisation_wavefront_changes_nothing(aoc, tuned):
+    """k_forward_lin (aoc_tuning.fw_lin): the nominal-point work of the small-batch forward pass on a wavefront of its
+    own, the LQR wavefront reduced to the recursion proper.  Same operations on the same values: iterates, steps, trial
+    counts, costs, descents and status flags must equal those of k_forward_split bit for bit — with 2, 3, 7 and all 10
+    candidates riding along (1 to 5 workgroups per tile, spare trial wavefronts, candidate stores with and without a
+    hint), on a ragged batch, across the Hessian switch, for an even and an odd number of stages and for a
+    caller-supplied fp64 initial iterate."""
+    from aircraftoptimalcontrol_amd import problems
+    for T, B in ((500, 200), (333, 70)):
+        pr = problems.step_maneuver(1.0, 1.0 / T)
+        assert pr.T == T
+        bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+        x0 = problems.random_x0(B, seed=23)
+        prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+        for ns in (2, 3, 7, 10):
+            res = []
+            for lin in (0, 1):
+                tuned(nspec=ns, fw_lin=lin)
+                s = aoc.NewtonBatchSolver(bp, B, prm)
+                s.set_initial_from_x0(x0)
+                res.append((s.run_fixed(11 if ns == 10 else 4), s.current(), s.direction()))
+            (ha, (xa, ua), da), (hb, (xb, ub), db) = res
+            assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(ua, ub, equal_nan=True), (T, ns)
+            assert np.array_equal(da, db, equal_nan=True), (T, ns)
+            for a, b in zip(ha, hb):
+                for key in a:
+                    assert np.array_equal(a[key], b[key], equal_nan=True), (T, ns, key)
+    # a caller-supplied iterate with arbitrary fp64 samples is read as fp64 by the first iteration
+    g = load_golden("g6_chain_step_T500")
+    pg = load_golden("problem_step_T500")
+    bp = aoc.BatchProblem(pg["QQt"], pg["RRt"], pg["QQT"], pg["xx_ref"], pg["uu_ref"], float(pg["dt"]))
+    out = []
+    for lin in (0, 1):
+        tuned(fw_lin=lin)
+        s = aoc.NewtonBatchSolver(bp, 3, aoc.make_params(stepsize_0=1.0, armijo_maxiters=10))
+        xi = np.repeat(g["xx_init"][None], 3, 0) * (1 + 1e-13 * np.arange(3)[:, None, None])
+        s.set_initial(xi, np.repeat(g["uu_init"][None], 3, 0))
+        s.iterate(0)
+        out.append((s.scalars(), s.current()))
+    for key in out[0][0]:
+        assert np.array_equal(out[0][0][key], out[1][0][key], equal_nan=True), key
+    assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
+
+
 def test_forward_state_recomputation_does_not_change_results(aoc, tuned):
     """aoc_forward re-computes the nominal states x_{t+1} = step(x_t, u_t) instead of reading them when the iterate is a
     rollout the library wrote (aoc_problem.x_is_rollout; one-wavefront-per-tile kernel): same operations as the rollout
