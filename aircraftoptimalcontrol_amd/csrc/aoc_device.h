@@ -144,20 +144,33 @@ __device__ __forceinline__ void sincos_lib(float x, float* sp, float* cp) { sinc
 // interleave); ONE rarely-taken branch afterwards redoes them with the library for huge finite
 // arguments.  (A wave-uniform shortcut for |angle| <= pi/4, where the reduction is the
 // identity, was measured and bought nothing: the extra branch costs what the dozen instructions save.)
-__device__ __forceinline__ SC trig(real th, real ga, const TrigK<real>& K = TrigK<real>()) {
+// trig() = trig_fast() + trig_fix() under trig_huge(); a kernel that evaluates several chains per stage (k_forward: the
+// nominal point and the Armijo trials) calls the fast parts of all of them first and guards ONE fix-up region with the OR
+// of the tests, so that the common path of the stage is one basic block the scheduler can interleave freely — with a
+// branch after every sin/cos pair the six polynomial evaluations of a stage sat in three blocks, one chain after the other.
+__device__ __forceinline__ SC trig_fast(real th, real ga, const TrigK<real>& K = TrigK<real>()) {
     SC s;
-    const real al = th - ga;
     sincos_fast(ga, &s.sg, &s.cg, K);
-    sincos_fast(al, &s.sa, &s.ca, K);
-    // finite and huge only: for NaN and +-inf the fast path already returns NaN, as sin/cos do.  (A diverged
-    // trajectory is NaN from some stage on; sending it through the library made its wavefront the straggler
-    // of the launch: 13 NaN trajectories in 65 536 cost the forward pass +55 %.)
-    const real aga = __builtin_fabs(ga), aal = __builtin_fabs(al), inf = __builtin_inf();
+    sincos_fast(th - ga, &s.sa, &s.ca, K);
+    return s;
+}
+// finite and huge only: for NaN and +-inf the fast path already returns NaN, as sin/cos do.  (A diverged
+// trajectory is NaN from some stage on; sending it through the library made its wavefront the straggler
+// of the launch: 13 NaN trajectories in 65 536 cost the forward pass +55 %.)
+__device__ __forceinline__ bool trig_huge(real th, real ga) {
+    const real aga = __builtin_fabs(ga), aal = __builtin_fabs(th - ga), inf = __builtin_inf();
     const real big = sizeof(real) == 8 ? R(1048576.0) : R(131072.0);  // where the Cody-Waite reduction stops being exact
-    if ((aga >= big && aga < inf) || (aal >= big && aal < inf)) {
+    return (aga >= big && aga < inf) || (aal >= big && aal < inf);
+}
+__device__ __forceinline__ void trig_fix(real th, real ga, SC& s) {
+    if (trig_huge(th, ga)) {
         sincos_lib(ga, &s.sg, &s.cg);
-        sincos_lib(al, &s.sa, &s.ca);
+        sincos_lib(th - ga, &s.sa, &s.ca);
     }
+}
+__device__ __forceinline__ SC trig(real th, real ga, const TrigK<real>& K = TrigK<real>()) {
+    SC s = trig_fast(th, ga, K);
+    trig_fix(th, ga, s);
     return s;
 }
 
@@ -459,7 +472,7 @@ __device__ __forceinline__ StageFlags lqr_stage_part(const KConst& k, const Lin&
     // can hand out each column of K~ as it goes: with the regularised gains patched in a branch AFTER the loop the
     // compiler kept M^-1 G, its negated copy and G alive side by side across that branch.
     real n00 = -i00, n01 = -i01, n11 = -i11;
-    if (!pd) {
+    if (!pd) {   // (a branch-free form — always evaluated, selected — was measured: no difference, 1.72 vs 1.72 ms)
         const real r00 = M00 + R(0.5), r11 = M11 + R(0.5);
         const real rdet = r00 * r11 - M01 * M01;
         if (rdet == R(0.0)) fl.singular = true;
