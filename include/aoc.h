@@ -290,7 +290,8 @@ int aoc_linesearch_update(const aoc_problem *prob, const aoc_params *prm, const 
  * (lqr_tracking.py:276), then the closed-loop nonlinear rollout u = u_opt + K (x - x_opt) from
  * x0_reg (= x_opt[:,0] + perturbation).  x_opt0 = sample 0 of x_opt, x0_reg: [ntiles][6][64] fp64.
  * Kgain: tiled C=12 (row 0 then row 1 of the 2x6 gain; sample T-1 zero).  x_reg/u_reg/x0_reg may be
- * NULL (gains only). */
+ * NULL (gains only).  No scratch and no workspace: every array of this call is a tiled trajectory array
+ * (aoc_tiled_elems) or a per-trajectory vector. */
 int aoc_lqr_tracking(const aoc_problem *prob, const void *x_opt, const double *u_opt, const double *x_opt0,
                      const double *x0_reg, double *Kgain, void *x_reg, double *u_reg, int32_t *status);
 

@@ -1,4 +1,4 @@
-"""Experiment: two half batches on two HIP streams against one full batch on one stream.
+"""Experiment (EXPERIMENTS.md): two half batches on two HIP streams against one full batch on one stream.
 The halves' kernels interleave on the GPU: while one half sits in its latency-bound line-search rounds the
 other streams.  Prints ms per iteration of the whole 131 072-trajectory shard for both arrangements."""
 import json
