@@ -61,8 +61,7 @@ class Tuning(C.Structure):
     """aoc_tuning (include/aoc.h): scheduling knobs; results never depend on them."""
     _fields_ = [(n, C.c_int32) for n in ("nspec", "split_tiles", "split_bw_tiles", "fw_lin", "ls_wcap", "ls_kgrow",
                                          "trial_split", "solve_norepack", "ls_worklist", "ls_cpl", "ls_depth_min",
-                                         "fw_recompute", "store_candidates", "bw4_tiles")] + \
-               [("reserved", C.c_int32 * 2)]
+                                         "fw_recompute", "store_candidates", "bw4_tiles", "bw5", "reserved")]
 
 
 # every symbol include/aoc.h declares: (name, restype, argtypes)

@@ -320,9 +320,10 @@ struct Lin {
     real b20, b50;
 };
 
-__device__ __forceinline__ Lin linearise(const KConst& k, const real x[6], real u0, const SC& s) {
+// (V, al = theta - gamma given: what the five-wavefront backward kernel hands from one producer to the other)
+__device__ __forceinline__ Lin linearise_va(const KConst& k, real V, real al, real u0, const SC& s) {
     Lin l;
-    const real V = x[2], al = x[3] - x[5], V2 = V * V;
+    const real V2 = V * V;
     const real iV = rcp_fast(V);
     const real dtmV = k.dtm * iV;                     // dt/(m V)
     l.a02 = k.dt * s.cg;
@@ -343,6 +344,9 @@ __device__ __forceinline__ Lin linearise(const KConst& k, const real x[6], real 
     l.b20 = k.dtm * s.ca;
     l.b50 = dtmV * s.sa;
     return l;
+}
+__device__ __forceinline__ Lin linearise(const KConst& k, const real x[6], real u0, const SC& s) {
+    return linearise_va(k, x[2], x[3] - x[5], u0, s);
 }
 
 // Second-order terms contracted with the costate (aircraft_simplified.py:339-388): the symmetric

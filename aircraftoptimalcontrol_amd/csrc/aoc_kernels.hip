@@ -114,6 +114,7 @@ static void tuning_defaults(aoc_tuning* t) {
     t->fw_recompute = env("AOC_FW_RECOMPUTE", 1);
     t->store_candidates = env("AOC_STORE_CANDIDATES", 1);
     t->bw4_tiles = env("AOC_BW4_TILES", 256);
+    t->bw5 = env("AOC_BW5", 1);
 }
 
 static const aoc_tuning& tuning() {

@@ -139,7 +139,8 @@ typedef struct aoc_tuning {
     int32_t store_candidates; /* AOC_STORE_CANDIDATES aoc_newton_iterate: small batches keep the trajectories of the Armijo candidates
                                rolled out in the forward pass, the update then copies the accepted one (1) */
     int32_t bw4_tiles;      /* AOC_BW4_TILES    Gauss-Newton backward pass on four wavefronts per tile (one producer, Riccati columns over three) up to this many tiles (256) */
-    int32_t reserved[2];
+    int32_t bw5;            /* AOC_BW5          ... with the producer itself on two wavefronts (five per tile, k_backward5) (1) */
+    int32_t reserved;
 } aoc_tuning;
 void aoc_get_tuning(aoc_tuning *out);
 void aoc_set_tuning(const aoc_tuning *t);

@@ -605,7 +605,7 @@ def test_speculation_depth_does_not_change_results(aoc, tuned):
 
 def test_split_kernels_equal_single_wavefront_kernels(aoc, tuned):
     """Small batches run the backward pass, the forward pass and the final rollout on several wavefronts per
-    tile (k_backward2, k_forward_split, k_ls_final_split); same operations on the same values, so the results
+    tile (k_backward2, k_backward4 / k_backward5, k_forward_split, k_ls_final_split); same operations on the same values, so the results
     must equal those of the one-wavefront-per-tile kernels bit for bit, across the full-Hessian switch."""
     from aircraftoptimalcontrol_amd import problems
     pr = problems.step_maneuver(1.0, 2e-3)
@@ -614,13 +614,17 @@ def test_split_kernels_equal_single_wavefront_kernels(aoc, tuned):
     x0 = problems.perturbed_x0(pr, B, seed=8)
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
     res = []
-    for tiles in (0, 512):
-        tuned(nspec=2, split_tiles=tiles, split_bw_tiles=tiles, ls_worklist=0)
+    for tiles, bw5 in ((0, 0), (512, 0), (512, 1)):     # one wavefront per tile | k_backward4 | k_backward5 in the Gauss-Newton iterations
+        tuned(nspec=2, split_tiles=tiles, split_bw_tiles=tiles, ls_worklist=0, bw5=bw5)
         s = aoc.NewtonBatchSolver(bp, B, prm)
         s.set_initial_from_x0(x0)
         res.append((s.run_fixed(11), s.current()))
-    (ha, (xa, ua)), (hb, (xb, ub)) = res
+    (ha, (xa, ua)), (hb, (xb, ub)), (hc, (xc, uc)) = res
     assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(ua, ub, equal_nan=True)
+    assert np.array_equal(xa, xc, equal_nan=True) and np.array_equal(ua, uc, equal_nan=True)
+    for a, c in zip(ha, hc):
+        for key in ("stepsize", "ntrials", "cost", "cost_new", "descent", "status"):
+            assert np.array_equal(a[key], c[key], equal_nan=True), key
     # the same for the tracking gains and the stored-state rollout (k_track_gains2/4, k_rollout_cost_split)
     tw = problems.tracking_weights()
     tp = aoc.BatchProblem(tw[0], tw[1], tw[2], pr.xx_ref, pr.uu_ref, pr.dt)

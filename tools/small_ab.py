@@ -8,7 +8,7 @@ import numpy as np
 import torch
 from aircraftoptimalcontrol_amd import _lib, batch as aoc, problems
 
-SETTINGS = [("default", {}), ("fw_lin", dict(fw_lin=1))]
+SETTINGS = [("bw4", dict(bw5=0)), ("bw5", dict(bw5=1))]
 
 
 def main():
