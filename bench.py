@@ -95,7 +95,8 @@ def kernel_names(ntiles, full):
     nspec = _lib.lib().aoc_default_nspec(ntiles * 64, 10)
     lin = t.fw_lin > 0 or (t.fw_lin < 0 and nspec <= 2)
     return {
-        "backward": "k_backward4<true, false, false, false, float>" if (not full and ntiles <= min(t.bw4_tiles, t.split_bw_tiles)) else
+        "backward": ("k_backward5<true, false, float>" if t.bw5 else "k_backward4<true, false, false, false, float>")
+                    if (not full and ntiles <= min(t.bw4_tiles, t.split_bw_tiles)) else
                     ("k_backward2<%s, float>" if ntiles <= t.split_bw_tiles else "k_backward<%s, float>") % fl,
         # <diagonal, shared reference, 2 speculated trials, states re-computed (the iterates of the run are rollouts), float32 states>
         "forward": ("k_forward_lin<true, false, float>" if lin else "k_forward_split<true, false, float>") if small else
