@@ -43,11 +43,15 @@ def main():
     IT = 5
     out = {"B": B, "T": pa.T, "iterations": IT, "settings": {}}
     ref = {}
-    for name, kn in SETTINGS:
+    # ONE solver per arithmetic type for every setting: the duration of a pass depends on where its buffers were allocated
+    # ("placement"), so a fresh solver per setting would compare allocations, not settings
+    s32 = batch.NewtonBatchSolverF32(bp, B, prm) if which in ("both", "f32") else None
+    s64 = batch.NewtonBatchSolver(bp, B, prm) if which in ("both", "f64") else None
+    for name, kn in SETTINGS + SETTINGS[:1]:
         row = {}
         with _lib.tuning(**kn):
-            if which in ("both", "f32"):
-                s = batch.NewtonBatchSolverF32(bp, B, prm)
+            if s32 is not None:
+                s = s32
                 best = None
                 for rep in range(3):
                     s.set_initial_rollout(x0, uu0)
@@ -59,10 +63,9 @@ def main():
                 row["f32_ms"] = round(best / IT * 1e3, 3)
                 J = s.scalars()["cost_new"]
                 row["f32_same"] = bool(np.array_equal(J, ref.setdefault("f32", J), equal_nan=True))
-                del s
-            if which in ("both", "f64"):
-                s = batch.NewtonBatchSolver(bp, B, prm)
-                best, passes = None, None
+            if s64 is not None:
+                s = s64
+                best = None
                 for rep in range(3):
                     s.set_initial_from_rollout(x0, uu0); s.ntrials.zero_()
                     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -78,9 +81,7 @@ def main():
                 torch.cuda.synchronize()
                 ms = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in evs]).mean(0)
                 row["f64_passes_ms"] = [round(float(v), 3) for v in ms]
-                del s
-            torch.cuda.empty_cache()
-        out["settings"][name] = row
+        out["settings"].setdefault(name, row)
         print(name, row, flush=True)
     print(json.dumps(out))
 
