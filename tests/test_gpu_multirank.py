@@ -138,3 +138,29 @@ print("RCCL_ONE_RANK_OK")
         env.pop(k, None)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL_ONE_RANK_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_best_placed_picks_a_solver_and_changes_no_result():
+    """batch.best_placed (allocation autotuning: build a few solvers, time a few iterations, keep the fastest) returns a
+    working solver of the kind asked for, reports one timing per candidate, and — the buffers holding the same values
+    wherever they were allocated — changes no result."""
+    from aircraftoptimalcontrol_amd import batch as aoc, problems
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 300
+    x0 = problems.random_x0(B, seed=5)
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    ref = aoc.NewtonBatchSolver(bp, B, prm)
+    ref.set_initial_from_x0(x0)
+    ref.run_fixed(4, record=False)
+    for make in (lambda: aoc.NewtonBatchSolver(bp, B, prm), lambda: aoc.TwoStreamNewtonSolver(bp, B, prm)):
+        sv, rep = aoc.best_placed(make, x0, candidates=3, probe_iters=2)
+        assert len(rep["ms_per_iteration"]) == 3 and 0 <= rep["chosen"] < 3 and min(rep["ms_per_iteration"]) > 0
+        assert rep["ms_per_iteration"][rep["chosen"]] == min(rep["ms_per_iteration"])
+        sv.set_initial_from_x0(x0)
+        sv.run_fixed(4) if isinstance(sv, aoc.TwoStreamNewtonSolver) else sv.run_fixed(4, record=False)
+        (xa, ua), (xb, ub) = ref.current(), sv.current()
+        assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(ua, ub, equal_nan=True)
+        a, b = ref.scalars(), sv.scalars()
+        for key in a:
+            assert np.array_equal(a[key], b[key], equal_nan=True), key
