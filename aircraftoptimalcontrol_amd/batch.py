@@ -724,8 +724,10 @@ def best_placed(make_solver, x0, candidates=5, probe_iters=6):
     the choice: the buffers hold the same values wherever they are.
     Returns (solver, {"ms_per_iteration": [...], "chosen": index})."""
     torch = _torch()
+    if int(candidates) <= 1:          # nothing to choose from: no probe either
+        return make_solver(), {"ms_per_iteration": [], "chosen": 0, "probe_iterations": 0}
     cands, ms = [], []
-    for _ in range(max(int(candidates), 1)):
+    for _ in range(int(candidates)):
         sv = make_solver()
         dev = sv.problem.device
         xd = _dev_f64(x0, dev)
