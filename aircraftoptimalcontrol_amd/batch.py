@@ -936,6 +936,9 @@ class NewtonBatchSolverF32:
                                            _ptr(self.ntrials), _ptr(self.status)), "aoc_newton_iterate_f32")
         self.cur, self.jcur, self.kk = n, jn, kk + 1
 
+    def join(self):
+        """(interface shared with TwoStreamNewtonSolver: one stream, nothing to wait for)"""
+
     def current(self):
         xx = unpack(self.xb[self.cur], self.B)
         xx[:, :, 0] = unpack_vec(self.x0, self.B).to(xx.dtype)
