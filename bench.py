@@ -378,15 +378,20 @@ def run(a):
     # iterations, the fastest is kept (batch.best_placed; the measurements are in `placement_tuning`).
     ncand = max(a.placement_candidates, 1)
     big = batch.ntiles(Bg) >= 1024
+    # all candidates are alive at once: never more than fit (a solver holds ~270 B per trajectory-stage: three iterates,
+    # K~, du, scratch), and one solver of each kind must remain possible
+    per_solver = 270.0 * Bg * T
+    fits = lambda: max(int(0.8 * torch.cuda.mem_get_info(dev)[0] / per_solver), 1)
     placement = {"candidates": ncand if big else 1}
     # one stream: the attribution pass, or everything with --no-overlap
-    s, placement["one_stream_solver"] = batch.best_placed(lambda: batch.NewtonBatchSolver(bp, Bg, prm), x0d,
-                                                          ncand if (big and a.no_overlap) else min(ncand, 3) if big else 1)
+    n1 = (ncand if a.no_overlap else min(ncand, 3)) if big else 1
+    s, placement["one_stream_solver"] = batch.best_placed(lambda: batch.NewtonBatchSolver(bp, Bg, prm), x0d, min(n1, fits()))
     # two half batches on two streams pay while each half is still a large-batch launch (one wavefront per tile kernels)
-    overlap = not a.no_overlap and s.nt >= 2048
+    overlap = not a.no_overlap and s.nt >= 2048 and fits() >= 1 and torch.cuda.mem_get_info(dev)[0] > 1.1 * per_solver
     s2 = None
     if overlap:
-        s2, placement["two_stream_solver"] = batch.best_placed(lambda: batch.TwoStreamNewtonSolver(bp, Bg, prm), x0d, ncand)
+        s2, placement["two_stream_solver"] = batch.best_placed(lambda: batch.TwoStreamNewtonSolver(bp, Bg, prm), x0d,
+                                                               min(ncand, fits()))
 
     def barrier():
         torch.cuda.synchronize(dev)

@@ -9,8 +9,14 @@ from oracle import oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def test_receding_horizon_vs_oracle():
+@pytest.mark.parametrize("large_batch_kernels", [False, True])
+def test_receding_horizon_vs_oracle(tuned, large_batch_kernels):
+    """large_batch_kernels: the one-wavefront-per-tile kernels and the three-launch path between two re-solves (plant step,
+    input shift, warm-start rollout: what batches above 512 tiles run) instead of the multi-wavefront kernels and the fused
+    k_mpc_warm_split of small batches — the same results either way."""
     from aircraftoptimalcontrol_amd import mpc, problems
+    if large_batch_kernels:
+        tuned(split_tiles=0, split_bw_tiles=0, nspec=2)
     T, L = 200, 260
     full = problems.step_maneuver(tf=1.0, dt=1.0 / L)      # a long reference curve to slide over
     pr = problems.ProblemData("mpc", full.QQt, full.RRt, full.QQT, full.xx_ref, full.uu_ref, full.tt, full.tf, full.dt)
