@@ -54,9 +54,14 @@ def _one_iteration_vs_oracle(aoc, bp, op, x0, kk, prm_kw, oprm_kw, n_iter=1):
     return s
 
 
+@pytest.mark.parametrize("large_batch_kernels", [False, True])
 @pytest.mark.parametrize("T", [3, 4, 5, 9, 17])
-def test_tiny_horizons(aoc, T):
+def test_tiny_horizons(aoc, tuned, T, large_batch_kernels):
+    """large_batch_kernels: the one-wavefront-per-tile kernels (k_backward with its peeled stage 0 and prefetch ring,
+    k_forward with two candidates riding along, k_ls_final) instead of the multi-wavefront ones a batch this small gets."""
     from aircraftoptimalcontrol_amd import problems
+    if large_batch_kernels:
+        tuned(split_tiles=0, split_bw_tiles=0, nspec=2, ls_worklist=1)
     pr, bp, op = _setup(aoc, T)
     x0 = problems.perturbed_x0(pr, 5, seed=T)
     kw = dict(stepsize_0=1.0, armijo_maxiters=10)
