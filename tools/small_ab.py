@@ -1,5 +1,6 @@
 """Small batches, a knob at a time: ms per Newton iteration (iterations 0..9 from perturbed x0) and per pass for a list
-of aoc_tuning settings.   python tools/small_ab.py B1 B2 ...   (settings: SETTINGS below)"""
+of aoc_tuning settings.   python tools/small_ab.py B1 B2 ... [knob=value,knob=value ...]   (settings after the sizes;
+"default" is always measured first)"""
 import sys
 import time
 
@@ -8,14 +9,14 @@ import numpy as np
 import torch
 from aircraftoptimalcontrol_amd import _lib, batch as aoc, problems
 
-SETTINGS = [("bw4", dict(bw5=0)), ("bw5", dict(bw5=1))]
+SETTINGS = [("default", {})] + [(a, {k: int(v) for k, v in (kv.split("=") for kv in a.split(","))}) for a in sys.argv[1:] if "=" in a]
 
 
 def main():
     pr = problems.step_maneuver(1.0, 2e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
-    for B in [int(a) for a in sys.argv[1:]] or [4096]:
+    for B in [int(a) for a in sys.argv[1:] if "=" not in a] or [4096]:
         x0 = torch.from_numpy(problems.perturbed_x0(pr, B, seed=20260401)).cuda()
         for name, kn in SETTINGS * 2:
             with _lib.tuning(**kn):
