@@ -55,6 +55,19 @@ def test_two_ranks_through_the_real_solver_equal_one_process(tmp_path):
     lo, hi = two["per_rank_ms_per_step"]
     assert 0 < lo <= hi and abs(hi - two["ms_per_step"]) < 1e-9
     assert one["collective"] is None and len(one["per_rank_ms_per_step"]) == 2
+    # the bench contract, key by key, on both lines
+    for line in (one, two):
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert key in line, key
+        assert line["higher_is_better"] is True and line["vs_baseline"] is None and line["dtype"] == "f64"
+        assert line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+        assert line["metric"].startswith("Newton iters/sec") and line["unit"] == "trajectory-Newton-iterations/s"
+        rf = line["roofline"]
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+        assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "traffic" in rf and rf["kernel"].startswith("k_")
+        assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+        assert abs(line["value"] - line["config"]["global_batch"] * line["steps"] / (line["ms_per_step"] * line["steps"] * 1e-3)) < 1e-6 * line["value"]
     out = os.path.join(ROOT, "gpurun_out", "two_rank_rehearsal.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump({"two_ranks_one_device_gloo": two, "one_process": one}, open(out, "w"), indent=1)
