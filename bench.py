@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the small configs reported beside the headline")
     ap.add_argument("--no-overlap", action="store_true",
                     help="one stream; the timed region itself carries the per-pass HIP events")
-    ap.add_argument("--placement-candidates", type=int, default=5,
+    ap.add_argument("--placement-candidates", type=int, default=7,
                     help="allocation autotuning before the run: build this many solvers, keep the fastest (batch.best_placed); "
                          "1 = take the buffers as first allocated")
     return ap.parse_args()
