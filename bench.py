@@ -376,7 +376,7 @@ def run(a):
     # pages an allocation happened to get (DRAM write-credit stalls, DESIGN.md section 4 "placement"), stable for its
     # lifetime, and worth 5-10 % between the best and a typical draw: a few solvers are built, each is timed over a few
     # iterations, the fastest is kept (batch.best_placed; the measurements are in `placement_tuning`).
-    ncand = max(a.placement_candidates, 1)
+    ncand = 1 if (one_dev and world > 1) else max(a.placement_candidates, 1)   # ranks sharing a device (rehearsal) do not compete for its memory
     big = batch.ntiles(Bg) >= 1024
     # all candidates are alive at once: never more than fit (a solver holds ~270 B per trajectory-stage: three iterates,
     # K~, du, scratch), and one solver of each kind must remain possible
