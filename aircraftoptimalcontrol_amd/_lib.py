@@ -13,6 +13,7 @@ _SRC = [os.path.join(_PKG, "csrc", f) for f in ("aoc_kernels.hip", "aoc_device.h
 _HDR = os.path.join(os.path.dirname(_PKG), "include", "aoc.h")
 
 AOC_TILE = 64
+AOC_ABI_VERSION = 4   # include/aoc.h: the revision this binding (struct layouts, argument lists) is written against
 
 # status flags (include/aoc.h)
 ST_NAN, ST_VNONPOS, ST_SINGULAR, ST_REGULARISED, ST_ARMIJO_EXH, ST_CONVERGED = 1, 2, 4, 8, 16, 32
@@ -61,7 +62,8 @@ class Tuning(C.Structure):
     """aoc_tuning (include/aoc.h): scheduling knobs; results never depend on them."""
     _fields_ = [(n, C.c_int32) for n in ("nspec", "split_tiles", "split_bw_tiles", "fw_lin", "ls_wcap", "ls_kgrow",
                                          "trial_split", "solve_norepack", "ls_worklist", "ls_cpl", "ls_depth_min",
-                                         "fw_recompute", "store_candidates", "bw4_tiles", "bw5", "reserved")]
+                                         "fw_recompute", "store_candidates", "bw4_tiles", "bw5", "solve_repack_pct",
+                                         "solve_sync_fast", "solve_split_tiles", "reserved")]
 
 
 # every symbol include/aoc.h declares: (name, restype, argtypes)
@@ -100,6 +102,11 @@ SYMBOLS = {
     "aoc_newton_iterate": (C.c_int, [_P, _P, _I] + [_P] * 5 + [_Z] + [_P] * 7),
     "aoc_solve_workspace_bytes": (_Z, [_I, _I]),
     "aoc_newton_solve": (C.c_int, [_P] * 6 + [_Z, _I] + [_P] * 10),
+    "aoc_newton_solve2": (C.c_int, [_P] * 6 + [_Z, _I] + [_P] * 11),
+    "aoc_abi_version": (_I, []),
+    "aoc_summary": (C.c_int, [_I, _P, _P, _P, _P, _I, _P]),
+    "aoc_solve_trace": (C.c_int, [_P, _I]),
+    "aoc_solve_trace_rows": (_I, []),
     "aoc_mpc_step": (C.c_int, [_P] * 3 + [_I] + [_P] * 6 + [_Z] + [_P] * 14),
     "aoc_traj_cost_f32": (C.c_int, [_P] * 5),
     "aoc_initial_trajectory_f32": (C.c_int, [_P, _D, _D, _P, _P, _P]),
@@ -130,6 +137,14 @@ def lib():
             l = C.CDLL(_SO)
         except OSError as e:  # e.g. ROCm runtime missing
             raise AocError("cannot load %s: %s" % (_SO, e))
+        try:
+            l.aoc_abi_version.restype = C.c_int32
+            have = int(l.aoc_abi_version())
+        except AttributeError:
+            have = None
+        if have != AOC_ABI_VERSION:   # an older or newer library would be handed shifted arguments
+            raise AocError("%s has ABI revision %s, this binding is written against %d (include/aoc.h AOC_ABI_VERSION): "
+                           "rebuild the library (__graft_entry__.build())" % (_SO, have, AOC_ABI_VERSION))
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)
             fn.restype = res

@@ -420,6 +420,18 @@ class NewtonBatchSolver:
         B = self.B
         return self.J[self.jcur][:B], self.descent[:B], self.ntrials[:B]
 
+    def summary(self, out=None, accumulate=False):
+        """sharding.SUMMARY_FIELDS of this batch as five fp64 scalars on the device, by aoc_summary (one kernel, fixed
+        reduction order); accumulate: added to what `out` holds.  What the path's one collective reduces."""
+        torch = _torch()
+        dev = self.problem.device
+        if out is None:
+            out = torch.zeros(5, dtype=torch.float64, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        check(lib().aoc_summary(self.B, _ptr(self.J[self.jcur]), _ptr(self.descent), _ptr(self.ntrials), _ptr(out),
+                                int(bool(accumulate)), st), "aoc_summary")
+        return out
+
     def run_fixed(self, n_iters, kk0=None, record=True):
         """n_iters iterations for every trajectory, no early exit (the bench mode)."""
         hist = []
@@ -549,11 +561,13 @@ class NewtonBatchSolver:
                     history={k_: np.stack(v, 1) if v else np.zeros((B, 0)) for k_, v in hist.items()},
                     last_kk=last)
 
-    def solve_on_device(self, sync_every=4, history=True, x_star_f64=False, to_host=True):
-        """solve() through aoc_newton_solve: the whole loop, stopping rule and return-index bookkeeping on
-        the device, the host only reads the count of still-iterating trajectories every `sync_every`
-        iterations (0: never; all max_iters-1 iterations run).  No re-packing: a stopped trajectory keeps
-        riding along in its tile.  Same return value as solve(); results are identical to solve(compact=False).
+    def solve_on_device(self, sync_every=4, history=True, x_star_f64=False, to_host=True, two_streams=True):
+        """solve() through aoc_newton_solve2: the whole loop, stopping rule and return-index bookkeeping on
+        the device; the host only reads the count of still-iterating trajectories (every `sync_every` iterations
+        while nobody has stopped, more often afterwards; 0: never, all max_iters-1 iterations run) to stop launching
+        and to re-pack the iterating trajectories into denser generations.  two_streams: large batches (aoc_tuning.
+        solve_split_tiles) are cut in two halves on two HIP streams that never wait for each other.
+        Same return value as solve(); results are identical to solve(compact=False).
         to_host=False leaves xx_star (B,6,T) / uu_star (B,2,T) on the device as torch tensors (copying 65 536
         trajectories to the host takes longer than solving them)."""
         torch = _torch()
@@ -570,11 +584,14 @@ class NewtonBatchSolver:
         hf = lambda dt: torch.empty((max(n_it, 1), self.Bp), dtype=dt, device=dev) if history else None
         hc, hd, hs, hn = hf(torch.float64), hf(torch.float64), hf(torch.float64), hf(torch.int32)
         n_run = C.c_int32(0)
+        if two_streams and getattr(self, "_stream2", None) is None:
+            self._stream2 = torch.cuda.Stream(device=dev)
+        st2 = C.c_void_p(self._stream2.cuda_stream) if two_streams else None
         torch.cuda.synchronize(dev)
         t_start = time.perf_counter()
-        check(lib().aoc_newton_solve(C.byref(p), C.byref(prm), _ptr(x), _ptr(self.ub[self.cur]), _ptr(self.x0), _ptr(ws), ws.numel() * 8,
-                                     int(sync_every), _ptr(x_star), _ptr(u_star), _ptr(iters), _ptr(ret), _ptr(status),
-                                     _ptr(hc), _ptr(hd), _ptr(hs), _ptr(hn), C.byref(n_run)), "aoc_newton_solve")
+        check(lib().aoc_newton_solve2(C.byref(p), C.byref(prm), _ptr(x), _ptr(self.ub[self.cur]), _ptr(self.x0), _ptr(ws), ws.numel() * 8,
+                                      int(sync_every), _ptr(x_star), _ptr(u_star), _ptr(iters), _ptr(ret), _ptr(status),
+                                      _ptr(hc), _ptr(hd), _ptr(hs), _ptr(hn), C.byref(n_run), st2), "aoc_newton_solve2")
         torch.cuda.synchronize(dev)
         t_device = time.perf_counter() - t_start   # the solve itself; the rest is unpacking and the copy to the host
         del ws
@@ -709,8 +726,15 @@ class TwoStreamNewtonSolver:
         cat = lambda f: torch.cat([f(sv)[:sv.B] for sv in self.parts])
         return cat(lambda sv: sv.J[sv.jcur]), cat(lambda sv: sv.descent), cat(lambda sv: sv.ntrials)
 
+    def summary(self, out=None):
+        """sharding.SUMMARY_FIELDS of the whole batch on the device (aoc_summary: first half, then the second half
+        accumulated), on the caller's stream after a join."""
+        self.join()
+        out = self.parts[0].summary(out)
+        return self.parts[1].summary(out, accumulate=True)
 
-def best_placed(make_solver, x0, candidates=5, probe_iters=6):
+
+def best_placed(make_solver, x0, candidates=5, probe_iters=6, keep_first=False):
     """Allocation autotuning for large fixed-iteration runs: build `candidates` solvers (make_solver() -> a
     NewtonBatchSolver or TwoStreamNewtonSolver, each with allocations of its own), time Newton iterations
     kk = 0..probe_iters-1 from x0 (B,6) on each, keep the fastest and free the others.
@@ -722,10 +746,18 @@ def best_placed(make_solver, x0, candidates=5, probe_iters=6):
     iterations in 4.96, 5.07, 5.47, 5.51 and 6.15 ms each, every time (tools/two_stream_lottery.py).  All candidates
     stay alive until the choice is made (a freed block would simply be handed out again).  Results do not depend on
     the choice: the buffers hold the same values wherever they are.
-    Returns (solver, {"ms_per_iteration": [...], "chosen": index})."""
+    Returns (solver, info) with info = {"ms_per_iteration": [...], "chosen": index, "probe_iterations", "probe_wall_s":
+    what the choice cost}.  keep_first: candidate 0 — the allocation a caller who does not choose gets — stays alive
+    too and is returned as info["first"] (the chosen solver itself when that is candidate 0), so that it can be timed on
+    the same workload."""
     torch = _torch()
+    t_wall = time.perf_counter()
     if int(candidates) <= 1:          # nothing to choose from: no probe either
-        return make_solver(), {"ms_per_iteration": [], "chosen": 0, "probe_iterations": 0}
+        sv = make_solver()
+        info = {"ms_per_iteration": [], "chosen": 0, "probe_iterations": 0, "probe_wall_s": 0.0}
+        if keep_first:
+            info["first"] = sv
+        return sv, info
     cands, ms = [], []
     for _ in range(int(candidates)):
         sv = make_solver()
@@ -745,10 +777,15 @@ def best_placed(make_solver, x0, candidates=5, probe_iters=6):
         cands.append(sv)
         ms.append(round(best, 3))
     chosen = int(np.argmin(ms))
-    keep = cands[chosen]
+    keep, first = cands[chosen], cands[0]
     del cands, sv
+    info = {"ms_per_iteration": ms, "chosen": chosen, "probe_iterations": probe_iters}
+    if keep_first:
+        info["first"] = first
+    del first
     torch.cuda.empty_cache()
-    return keep, {"ms_per_iteration": ms, "chosen": chosen, "probe_iterations": probe_iters}
+    info["probe_wall_s"] = round(time.perf_counter() - t_wall, 3)
+    return keep, info
 
 
 def traj_cost(problem, xx, uu):

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "../../include/aoc.h"
 
@@ -69,6 +70,43 @@ __global__ void k_unpack(int B, int T, int C, const ET* __restrict__ src, double
 }
 
 // ---------------------------------------------------------------------------------------------
+// Scalar summary of a shard (aoc_summary): what the path's one collective reduces over the ranks.  One workgroup of
+// 1024 threads, a fixed reduction tree: the sums are the same bits from run to run (no atomics).
+// out[0] += sum of the finite costs, out[1] += sum of the descents of those trajectories, out[2] += sum of the trial
+// counts, out[3] += B, out[4] += number of non-finite costs.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_summary(int B, const double* __restrict__ cost, const double* __restrict__ descent,
+                                                   const int* __restrict__ ntrials, double* __restrict__ out, int accumulate) {
+    __shared__ double sh[3][16];
+    __shared__ long long shi[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double sc = 0.0, sd = 0.0;
+    long long st = 0, nn = 0;
+    for (int i = tid; i < B; i += 1024) {
+        const double c = cost[i];
+        const bool ok = __builtin_isfinite(c);
+        if (ok) { sc += c; sd += descent[i]; } else nn++;
+        st += ntrials[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sc += __shfl_down(sc, off);
+        sd += __shfl_down(sd, off);
+        st += __shfl_down(st, off);
+        nn += __shfl_down(nn, off);
+    }
+    if (lane == 0) { sh[0][wv] = sc; sh[1][wv] = sd; shi[0][wv] = st; shi[1][wv] = nn; }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        long long c = 0, d = 0;
+        for (int w = 0; w < 16; w++) { a += sh[0][w]; b += sh[1][w]; c += shi[0][w]; d += shi[1][w]; }
+        if (accumulate) { out[0] += a; out[1] += b; out[2] += (double)c; out[3] += (double)B; out[4] += (double)d; }
+        else { out[0] = a; out[1] = b; out[2] = (double)c; out[3] = (double)B; out[4] = (double)d; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side common to both arithmetic types
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_hip_err[256] = "";
@@ -115,6 +153,9 @@ static void tuning_defaults(aoc_tuning* t) {
     t->store_candidates = env("AOC_STORE_CANDIDATES", 1);
     t->bw4_tiles = env("AOC_BW4_TILES", 256);
     t->bw5 = env("AOC_BW5", 1);
+    t->solve_repack_pct = env("AOC_SOLVE_REPACK_PCT", 70);
+    t->solve_sync_fast = env("AOC_SOLVE_SYNC_FAST", 2);
+    t->solve_split_tiles = env("AOC_SOLVE_SPLIT_TILES", 2048);
 }
 
 static const aoc_tuning& tuning() {
@@ -145,6 +186,11 @@ static int check_problem(const aoc_problem* p) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Diagnostic timeline of aoc_newton_solve (aoc_solve_trace, include/aoc.h): one row per iteration launched.
+struct SolveTrace { double* rows; int cap; int n; };
+constexpr int SOLVE_TRACE_COLS = 6;   // part, kk, batch in flight, tiles in flight, still iterating as the host last read it (-1: not read), ms since the start
+static SolveTrace g_solve_trace = {nullptr, 0, 0};
+
 // forward declarations used by the launch functions
 extern "C" int32_t aoc_ntiles(int32_t B);
 extern "C" size_t aoc_tiled_elems(int32_t B, int32_t T, int32_t C);
@@ -170,7 +216,8 @@ constexpr int AOC_SPEC_MAX = 15;   // Armijo candidates that may ride along in t
 
 extern "C" {
 
-const char* aoc_version(void) { return "aoc-hip 0.1 (gfx950)"; }
+const char* aoc_version(void) { return "aoc-hip 0.4 (gfx950)"; }
+int32_t aoc_abi_version(void) { return AOC_ABI_VERSION; }
 
 const char* aoc_strerror(int code) {
     switch (code) {
@@ -339,8 +386,30 @@ int aoc_newton_solve(const aoc_problem* p, const aoc_params* prm, const void* x_
                      double* u_star, int32_t* iters, int32_t* ret_index, int32_t* status, double* hist_cost,
                      double* hist_descent, double* hist_stepsize, int32_t* hist_ntrials, int32_t* n_run) {
     return aoc64::api_newton_solve(p, prm, x_init, u_init, x0, workspace, workspace_bytes, sync_every, x_star, u_star, iters, ret_index,
-                                   status, hist_cost, hist_descent, hist_stepsize, hist_ntrials, n_run);
+                                   status, hist_cost, hist_descent, hist_stepsize, hist_ntrials, n_run, nullptr);
 }
+int aoc_newton_solve2(const aoc_problem* p, const aoc_params* prm, const void* x_init, const double* u_init,
+                      const double* x0, void* workspace, size_t workspace_bytes, int32_t sync_every, void* x_star,
+                      double* u_star, int32_t* iters, int32_t* ret_index, int32_t* status, double* hist_cost,
+                      double* hist_descent, double* hist_stepsize, int32_t* hist_ntrials, int32_t* n_run, void* stream2) {
+    return aoc64::api_newton_solve(p, prm, x_init, u_init, x0, workspace, workspace_bytes, sync_every, x_star, u_star, iters, ret_index,
+                                   status, hist_cost, hist_descent, hist_stepsize, hist_ntrials, n_run, stream2);
+}
+
+int aoc_summary(int32_t B, const double* cost, const double* descent, const int32_t* ntrials, double* out5,
+                int32_t accumulate, void* stream) {
+    if (B < 1 || !cost || !descent || !ntrials || !out5) return einval("aoc_summary: NULL argument or B < 1");
+    hipLaunchKernelGGL(k_summary, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, cost, descent, ntrials, out5, accumulate);
+    return check_launch("k_summary");
+}
+
+int aoc_solve_trace(double* rows, int32_t cap_rows) {
+    g_solve_trace.rows = rows;
+    g_solve_trace.cap = rows ? cap_rows : 0;
+    g_solve_trace.n = 0;
+    return AOC_OK;
+}
+int32_t aoc_solve_trace_rows(void) { return g_solve_trace.n; }
 
 int aoc_mpc_step(const aoc_problem* p_track, const aoc_problem* p_next, const aoc_params* prm, int32_t n_newton,
                  const void* x_cur, const double* u_cur, double* x0, double* x_true, const double* disturbance,

@@ -47,6 +47,14 @@
 extern "C" {
 #endif
 
+/* Revision of this ABI: bumped whenever a struct layout, an argument list or the meaning of a size query changes.
+ * aoc_abi_version() returns the value the library was built with; a binding compares it with the header (or the
+ * constant) it was written against and refuses to run on a mismatch instead of passing shifted arguments.
+ *   3: round 3 (scratch_bytes / cand_bytes on the pass-level entries; aoc_workspace_bytes(B,T) covers exactly B)
+ *   4: aoc_tuning + solve_repack_pct / solve_sync_fast / solve_split_tiles; aoc_newton_solve2, aoc_summary,
+ *      aoc_solve_trace, aoc_abi_version; aoc_solve_workspace_bytes includes a fourth iterate buffer */
+#define AOC_ABI_VERSION 4
+
 #define AOC_TILE 64
 #define AOC_NS 6
 #define AOC_NI 2
@@ -140,12 +148,16 @@ typedef struct aoc_tuning {
                                rolled out in the forward pass, the update then copies the accepted one (1) */
     int32_t bw4_tiles;      /* AOC_BW4_TILES    Gauss-Newton backward pass on four wavefronts per tile (one producer, Riccati columns over three) up to this many tiles (256) */
     int32_t bw5;            /* AOC_BW5          ... with the producer itself on two wavefronts (five per tile, k_backward5) (1) */
+    int32_t solve_repack_pct;  /* AOC_SOLVE_REPACK_PCT  aoc_newton_solve re-packs when at most this per cent of the batch in flight still iterates (70) */
+    int32_t solve_sync_fast;   /* AOC_SOLVE_SYNC_FAST   ... and reads the count every this many iterations once trajectories have begun to stop (2) */
+    int32_t solve_split_tiles; /* AOC_SOLVE_SPLIT_TILES aoc_newton_solve2 cuts batches of at least this many tiles in two halves on its two streams (2048) */
     int32_t reserved;
 } aoc_tuning;
 void aoc_get_tuning(aoc_tuning *out);
 void aoc_set_tuning(const aoc_tuning *t);
 
 const char *aoc_version(void);
+int32_t aoc_abi_version(void);   /* AOC_ABI_VERSION of the library's build */
 const char *aoc_strerror(int code);
 const char *aoc_last_hip_error(void);
 /* number of doubles in a tiled array of C components: ntiles*T*C*64 */
@@ -362,6 +374,36 @@ int aoc_newton_solve(const aoc_problem *prob, const aoc_params *prm, const void 
                      const double *x0, void *workspace, size_t workspace_bytes, int32_t sync_every, void *x_star, double *u_star,
                      int32_t *iters, int32_t *ret_index, int32_t *status, double *hist_cost,
                      double *hist_descent, double *hist_stepsize, int32_t *hist_ntrials, int32_t *n_run);
+
+/* Scalar summary of a shard — the five numbers the path's only collective reduces over the GPUs of a node (SURVEY 8e;
+ * no reference counterpart: the reference prints one trajectory's cost and descent per iteration, optcon.py:497-498):
+ *   out5[0] = sum of the finite costs, [1] = sum of the descents of those trajectories, [2] = sum of the Armijo trial
+ *   counts, [3] = B, [4] = number of trajectories whose cost is not finite;   accumulate != 0 adds to what out5 holds
+ * (a shard kept as several batches: one call per batch, in a fixed order).  cost, descent, ntrials: per-trajectory
+ * device arrays as aoc_newton_iterate fills them (the first B entries are read); out5: DEVICE, five doubles.  One
+ * workgroup with a fixed reduction order: the same bits from run to run. */
+int aoc_summary(int32_t B, const double *cost, const double *descent, const int32_t *ntrials, double *out5,
+                int32_t accumulate, void *stream);
+
+/* aoc_newton_solve with a second stream: batches of at least aoc_tuning.solve_split_tiles tiles are cut in two halves
+ * (by tiles), each solved as aoc_newton_solve would solve it — generations, re-packing, histories — the first on
+ * prob->stream, the second on stream2, driven by this one host thread: while it waits for one half's counter the other
+ * half's launches are queued.  stream2 first waits for what the caller queued on prob->stream, and prob->stream
+ * continues after both halves, so the call orders like aoc_newton_solve.  Same results (per-trajectory results never
+ * depend on the batch a trajectory is solved in).  stream2 = NULL, or a smaller batch: exactly aoc_newton_solve. */
+int aoc_newton_solve2(const aoc_problem *prob, const aoc_params *prm, const void *x_init, const double *u_init,
+                      const double *x0, void *workspace, size_t workspace_bytes, int32_t sync_every, void *x_star, double *u_star,
+                      int32_t *iters, int32_t *ret_index, int32_t *status, double *hist_cost,
+                      double *hist_descent, double *hist_stepsize, int32_t *hist_ntrials, int32_t *n_run, void *stream2);
+
+/* Diagnostic (no reference counterpart): timeline of the aoc_newton_solve calls that follow.  rows: HOST memory for
+ * cap_rows rows of 6 doubles — part (0, or 1 = the half on stream2), iteration kk, trajectories in flight in that
+ * iteration (the generation's batch), its tiles, the count of still-iterating trajectories if the host read it after
+ * that iteration (else -1), milliseconds from the start of the solve to the end of that iteration's launches (HIP
+ * events on the part's stream; one more row per part closes the final bookkeeping).  NULL switches the trace off.  aoc_solve_trace_rows(): rows the last solve wrote.
+ * Process-wide like aoc_set_tuning; tracing adds one event record per iteration and one synchronisation at the end. */
+int aoc_solve_trace(double *rows, int32_t cap_rows);
+int32_t aoc_solve_trace_rows(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Receding horizon (BASELINE.json configs[4]; the reference has no MPC, the loop is SURVEY 8d's "Config 5"

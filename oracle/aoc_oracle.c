@@ -729,7 +729,7 @@ int orc_lqr_tracking(const orc_model *md, int T, const double *QQt, const double
  * ------------------------------------------------------------------------------------------ */
 int orc_newton_iterate_batch(const orc_problem *p, const orc_params *prm, int B, int kk0, int n_iters,
                              double *xx, double *uu, const double *x0, double *JJ, double *descent,
-                             double *stepsize, int32_t *ntrials, int nthreads) {
+                             double *stepsize, int32_t *ntrials, int32_t *nreg, int nthreads) {
     const int T = p->T;
     int nsing = 0;
 #ifdef _OPENMP
@@ -740,9 +740,10 @@ int orc_newton_iterate_batch(const orc_problem *p, const orc_params *prm, int B,
         double *un = (double *)malloc((size_t)2 * T * sizeof(double));
         double *xb = xx + (size_t)b * 6 * T, *ub = uu + (size_t)b * 2 * T;
         for (int it = 0; it < n_iters; it++) {
-            double J, d, s; int ntr;
+            double J, d, s; int ntr, nr = 0;
             nsing += orc_newton_iterate(p, prm, kk0 + it, xb, ub, x0 + (size_t)b * 6, xn, un, &J, &d, &s, &ntr,
-                                        NULL, NULL, NULL, NULL, NULL);
+                                        &nr, NULL, NULL, NULL, NULL);
+            if (nreg) nreg[(size_t)b * n_iters + it] = nr;   /* stages whose M was regularised (optcon.py:745-749) */
             memcpy(xb, xn, (size_t)6 * T * sizeof(double)); memcpy(ub, un, (size_t)2 * T * sizeof(double));
             if (JJ) JJ[(size_t)b * n_iters + it] = J;
             if (descent) descent[(size_t)b * n_iters + it] = d;

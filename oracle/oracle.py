@@ -219,8 +219,9 @@ def newton_iterate_batch(prob, prm, xx, uu, x0, kk0, n_iters, nthreads=0):
     B = xx.shape[0]
     J = np.zeros((B, n_iters)); d = np.zeros((B, n_iters)); s = np.zeros((B, n_iters))
     n = np.zeros((B, n_iters), np.int32)
+    nreg = np.zeros((B, n_iters), np.int32)     # stages whose M was regularised in that iteration (optcon.py:745-749)
     if nthreads <= 0:
         nthreads = lib().orc_max_threads()
     ns = lib().orc_newton_iterate_batch(C.byref(prob.c), C.byref(prm), B, int(kk0), int(n_iters), _p(xx), _p(uu),
-                                        _p(_f64(x0)), _p(J), _p(d), _p(s), _p(n), int(nthreads))
-    return dict(cost=J, descent=d, stepsize=s, ntrials=n, nsing=ns, nthreads=nthreads)
+                                        _p(_f64(x0)), _p(J), _p(d), _p(s), _p(n), _p(nreg), int(nthreads))
+    return dict(cost=J, descent=d, stepsize=s, ntrials=n, nreg=nreg, nsing=ns, nthreads=nthreads)

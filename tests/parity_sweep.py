@@ -44,6 +44,8 @@ def sweep(aoc, problems, B=4096, n_it=12, dist="random", prob="step", seed=4242,
         elem = (d / np.maximum(np.abs(Uf), 1e-3)).max(axis=(1, 2))
         chan = (d.max(axis=2) / np.maximum(np.abs(Uf).max(axis=2), 1e-3)).max(axis=1)
         flagged = (sc["status"] & (4 | 8)) != 0       # singular / regularised gains in this iteration
+        reg_g = (sc["status"] & 8) != 0               # GPU: M + 0.5 I applied at some stage of this iteration (optcon.py:745-749)
+        reg_o = r["nreg"][:, 0] > 0                   # oracle: the same, counted per stage
         s.status.zero_()
         x_same = np.array([np.array_equal(xn[b], X[b], equal_nan=True) for b in range(B)])
         ok = step_eq & ntr_eq & fin                   # same Armijo verdicts: the iterates are comparable
@@ -54,6 +56,14 @@ def sweep(aoc, problems, B=4096, n_it=12, dist="random", prob="step", seed=4242,
             cost_rel_max=mx(np.abs(r["cost"][:, 0] - sc["cost"]) / np.abs(sc["cost"]), fin),
             descent_rel_max=mx(np.abs(r["descent"][:, 0] - sc["descent"]) / np.abs(sc["descent"]), fin & ~flagged),
             n_regularised=int(flagged.sum()),
+            # the regularisation branch itself: which trajectories took it, on the device and in the oracle (finite ones)
+            n_regularised_gpu=int((reg_g & fin).sum()), n_regularised_oracle=int((reg_o & fin).sum()),
+            n_regularised_set_difference=int(((reg_g != reg_o) & fin).sum()),
+            # who diverges in THIS iteration: a new iterate (states or inputs) that is not finite, on either side
+            nonfinite_gpu=int((~(np.isfinite(xn).all((1, 2)) & np.isfinite(un).all((1, 2)))).sum()),
+            nonfinite_oracle=int((~(np.isfinite(X).all((1, 2)) & np.isfinite(U).all((1, 2)))).sum()),
+            nonfinite_set_difference=int(((np.isfinite(xn).all((1, 2)) & np.isfinite(un).all((1, 2))) !=
+                                          (np.isfinite(X).all((1, 2)) & np.isfinite(U).all((1, 2)))).sum()),
             u_channel_rel_max=mx(chan, ok), u_channel_rel_max_unflagged=mx(chan, ok & ~flagged),
             u_elementwise_rel_max_unflagged=mx(elem, ok & ~flagged), u_elementwise_rel_median=float(np.median(elem[ok])) if ok.any() else 0.0,
             u_elementwise_rel_p999=float(np.percentile(elem[ok], 99.9)) if ok.any() else 0.0,

@@ -571,6 +571,103 @@ def test_device_solve_with_repacking(aoc):
     _same_solve(host, dev)
 
 
+def _solve_trace(aoc, s, **kw):
+    """solve_on_device under aoc_solve_trace: (result, rows [part, kk, in flight, tiles, count read, ms])"""
+    import ctypes as C
+    from aircraftoptimalcontrol_amd._lib import lib
+    rows = np.zeros((512, 6))
+    lib().aoc_solve_trace(rows.ctypes.data_as(C.c_void_p), rows.shape[0])
+    try:
+        r = s.solve_on_device(**kw)
+        n = lib().aoc_solve_trace_rows()
+    finally:
+        lib().aoc_solve_trace(None, 0)
+    return r, rows[:n].copy()
+
+
+def test_device_solve_retires_the_all_nan_fixed_point(aoc):
+    """A diverged trajectory never passes the reference's stopping test (NaN >= -1e-6 is False, optcon.py:499) and
+    iterates to max_iters on an iterate that no longer changes.  aoc_newton_solve retires it once one iteration has
+    run on that all-NaN iterate, with exactly what the remaining iterations would have produced: from random x0 a few
+    per cent of the batch diverge at the Hessian switch (kk = 9); the device solve must equal the host loop — which
+    really runs every iteration — bit for bit (iterates, iteration counts = max_iters - 1, status flags, histories up to
+    the last row), while its timeline shows that it stopped launching long before max_iters."""
+    from aircraftoptimalcontrol_amd import problems
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 2600
+    x0 = problems.random_x0(B, seed=20260403)
+    prm = aoc.make_params(max_iters=70, stepsize_0=1.0, armijo_maxiters=10)
+    s = aoc.NewtonBatchSolver(bp, B, prm)
+    s.set_initial_from_x0(x0)
+    host = s.solve(compact=False)
+    s.set_initial_from_x0(x0)
+    dev, rows = _solve_trace(aoc, s, sync_every=2)
+    nan = np.isnan(host["uu_star"][:, :, :-1]).all((1, 2))
+    assert 10 < nan.sum() < B // 4, "the case needs diverged trajectories"
+    assert (host["iters"][nan] == prm.max_iters - 1).all() and not host["converged"][nan].any()
+    assert host["last_kk"] == prm.max_iters - 2
+    _same_solve(host, dev)
+    launched = int(rows[rows[:, 1] >= 0, 1].max()) + 1
+    assert launched < prm.max_iters - 10, "the retired trajectories should not keep the batch iterating (%d launched)" % launched
+
+
+def test_device_solve_on_two_streams_equals_one(aoc, tuned):
+    """aoc_newton_solve2 cuts a large batch in two halves on two HIP streams (each with its own generations and
+    re-packing); with the threshold lowered so that 6000 trajectories split (47 + 47 tiles, the second half ragged), the
+    results — iterates, counts, flags, histories — equal the one-stream solve bit for bit, and the timeline shows both
+    parts at work.  Shared and per-trajectory reference curves (the second half reads its curves at a tile offset)."""
+    from aircraftoptimalcontrol_amd import problems
+    pr = problems.step_maneuver(1.0, 2e-3)
+    B = 6000
+    x0 = problems.perturbed_x0(pr, B, seed=77)
+    prm = aoc.make_params(max_iters=40, stepsize_0=1.0, armijo_maxiters=10)
+    XR, UR = np.repeat(pr.xx_ref[None], B, 0), np.repeat(pr.uu_ref[None], B, 0)
+    XR[B // 3:, 1] *= 0.9                       # two manoeuvres, the cut between the halves falls inside the second
+    for bp in (aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt),
+               aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, XR, UR, pr.dt)):
+        s = aoc.NewtonBatchSolver(bp, B, prm)
+        s.set_initial_from_x0(x0)
+        one = s.solve_on_device(sync_every=2, two_streams=False)
+        tuned(solve_split_tiles=2)
+        s.set_initial_from_x0(x0)
+        two, rows = _solve_trace(aoc, s, sync_every=2, two_streams=True)
+        tuned()
+        assert sorted(set(rows[:, 0].astype(int))) == [0, 1]
+        assert rows[rows[:, 0] == 0, 2].max() == 47 * 64 and rows[rows[:, 0] == 1, 2].max() == B - 47 * 64
+        assert one["converged"].sum() > B // 2
+        _same_solve(one, two)
+        if bp.per_traj:   # lane b must keep reading curve b: a batch with its own curves is never re-packed (it was, in round 3)
+            s.set_initial_from_x0(x0)
+            _same_solve(s.solve(compact=False), one)
+
+
+def test_device_summary_equals_the_host_summary(aoc):
+    """aoc_summary (the five scalars the path's one collective reduces) against sharding.local_summary on the same
+    per-trajectory arrays, non-finite costs included; two batches accumulated = the whole."""
+    import torch
+    from aircraftoptimalcontrol_amd import problems, sharding
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 1500
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    s = aoc.NewtonBatchSolver(bp, B, prm)
+    s.set_initial_from_x0(problems.random_x0(B, seed=20260403))
+    for kk in range(11):
+        s.iterate(kk)
+    ref = sharding.local_summary(*s.summary_tensors()).cpu().numpy()
+    got = s.summary().cpu().numpy()
+    assert ref[4] > 0 and got[3] == B and got[4] == ref[4] and got[2] == ref[2]
+    assert np.allclose(got[:2], ref[:2], rtol=1e-13, atol=0)
+    assert np.array_equal(s.summary().cpu().numpy(), got)            # a fixed reduction order: the same bits again
+    t = aoc.TwoStreamNewtonSolver(bp, B, prm)
+    t.set_initial_from_x0(torch.from_numpy(problems.random_x0(B, seed=20260403)).cuda())
+    for kk in range(11):
+        t.iterate(kk)
+    both = t.summary().cpu().numpy()
+    assert both[3] == B and both[4] == ref[4] and both[2] == ref[2] and np.allclose(both[:2], ref[:2], rtol=1e-13, atol=0)
+
+
 def test_speculation_depth_does_not_change_results(aoc, tuned):
     """How many Armijo candidates ride along in the forward pass is a scheduling decision: 1, 2, 3 (one wavefront
     per tile or one per chain) and all 10 (tiny batches: several workgroups per tile, no trial round at all) must
