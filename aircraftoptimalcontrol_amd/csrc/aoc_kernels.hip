@@ -287,8 +287,16 @@ int32_t aoc_default_nspec(int32_t B, int32_t armijo_maxiters) {
     // per CU, i.e. tiles x groups <= 512.  Measured, ms per iteration with 2 candidates -> with this rule:
     // 4096 trajectories 1.85 -> 1.44 (all 10), 8192 1.89 -> 1.58 (10), 10 240 1.81 -> 1.47 (9), 16 384 1.86 -> 1.78 (6);
     // one group more than the rule allows: 12 288 with 9 candidates 1.92, 16 384 with 10 2.21.
+    // When every candidate rides along, so does the step an EXHAUSTED search applies — stepsize_0 * beta^armijo_maxiters,
+    // never judged (Q5, optcon.py:327), candidate index armijo_maxiters: its trajectory is then stored like the others
+    // and the update of a tile with exhausted searches is a copy too, not one more serial rollout (the tail of a
+    // converge-mode solve and the storms of near-converged batches exhaust half of their searches).
     if (armijo_maxiters >= 1 && armijo_maxiters <= AOC_SPEC_MAX) {
-        long g = (armijo_maxiters + 2) / 3;
+        const long m1 = armijo_maxiters + 1 <= AOC_SPEC_MAX ? armijo_maxiters + 1 : armijo_maxiters;
+        long g = (m1 + 2) / 3;
+        if (512 / nt < g) g = 512 / nt;
+        if (g >= 2 && 3 * g >= m1) return (int32_t)m1;
+        g = (armijo_maxiters + 2) / 3;
         if (512 / nt < g) g = 512 / nt;
         if (g >= 2) return 3 * g < armijo_maxiters ? (int32_t)(3 * g) : armijo_maxiters;
     }

@@ -505,9 +505,9 @@ def run(a):
                 "us": float(np.mean(ts) * 1e6), "us_min": float(np.min(ts) * 1e6), "repeats": len(ts),
                 "device_per_rank": "cuda:0 for every rank (one-GPU rehearsal)" if one_dev else "cuda:LOCAL_RANK"}
     if os.environ.get("AOC_BENCH_DUMP"):   # tests: this rank's per-trajectory results after the K iterations
-        xx, uu = res.current()
-        np.savez(os.path.join(os.environ["AOC_BENCH_DUMP"], "rank%d_of_%d.npz" % (rank, world)), first=first, xx=xx, uu=uu,
-                 summary=summ.cpu().numpy(), **sc)
+        full = {} if os.environ.get("AOC_BENCH_DUMP_LIGHT") == "1" else dict(zip(("xx", "uu"), res.current()))   # light: scalars only
+        np.savez(os.path.join(os.environ["AOC_BENCH_DUMP"], "rank%d_of_%d.npz" % (rank, world)), first=first,
+                 summary=summ.cpu().numpy(), **full, **sc)
     if world > 1:   # nothing below talks to another rank: rank 0 alone finishes the record
         barrier()
         dist.destroy_process_group()

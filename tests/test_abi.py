@@ -75,9 +75,10 @@ def test_default_speculation_depth_is_host_logic(tuned):
     lib = _lib.lib()
     assert lib.aoc_spec_max() >= 10
     tuned(nspec=0)
-    for B, m, want in ((1, 10, 10), (4096, 10, 10), (8192, 10, 10), (8193, 10, 9), (10880, 10, 9), (10881, 10, 6),
+    # where every candidate rides along, so does the step an exhausted search applies (index armijo_maxiters): m + 1
+    for B, m, want in ((1, 10, 11), (4096, 10, 11), (8192, 10, 11), (8193, 10, 9), (10880, 10, 9), (10881, 10, 6),
                        (16384, 10, 6), (16385, 10, 2), (131072, 10, 2), (64, 20, 2), (64, 1, 1), (64, 2, 2),
-                       (64, 4, 4), (64, 12, 12)):
+                       (64, 4, 5), (64, 12, 13), (64, 15, 15), (64, 14, 15)):
         assert lib.aoc_default_nspec(B, m) == want, (B, m, lib.aoc_default_nspec(B, m), want)
     tuned(nspec=3)
     assert lib.aoc_default_nspec(131072, 10) == 3

@@ -678,9 +678,9 @@ def test_speculation_depth_does_not_change_results(aoc, tuned):
     B = 300
     x0 = problems.random_x0(B, seed=31)
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
-    assert _lib.lib().aoc_default_nspec(B, 10) == 10 and _lib.lib().aoc_default_nspec(200000, 10) == 2
+    assert _lib.lib().aoc_default_nspec(B, 10) == 11 and _lib.lib().aoc_default_nspec(200000, 10) == 2
     res = {}
-    for ns, wl in ((1, 0), (2, 0), (3, 0), (10, 0), (7, 0), (2, 1), (3, 1)):
+    for ns, wl in ((1, 0), (2, 0), (3, 0), (10, 0), (11, 0), (7, 0), (2, 1), (3, 1)):
         tuned(nspec=ns, ls_worklist=wl)
         s = aoc.NewtonBatchSolver(bp, B, prm)
         assert s.n_spec == ns
