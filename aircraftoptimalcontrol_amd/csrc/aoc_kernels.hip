@@ -156,6 +156,8 @@ static void tuning_defaults(aoc_tuning* t) {
     t->solve_repack_pct = env("AOC_SOLVE_REPACK_PCT", 70);
     t->solve_sync_fast = env("AOC_SOLVE_SYNC_FAST", 2);
     t->solve_split_tiles = env("AOC_SOLVE_SPLIT_TILES", 2048);
+    t->track_hcut = env("AOC_TRACK_HCUT", -1);
+    t->bw_hcut = env("AOC_BW_HCUT", -1);
 }
 
 static const aoc_tuning& tuning() {

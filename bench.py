@@ -473,10 +473,14 @@ def run(a):
     else:
         el, every, summ, evs = timed_region(s, lambda k: s.iterate_timed(k))
     # the same K iterations on the allocation as FIRST made (what a caller of the API gets without best_placed)
-    if sv_first is None or sv_first is res:
+    # (timed_region holds collectives: every rank must take the same branch, whatever ITS choice was — a rank whose chosen
+    # candidate is its first one times it once more)
+    if placement["candidates"] <= 1:
         el_first = el
     else:
-        el_first = timed_region(sv_first, lambda k: sv_first.iterate(k))[0]
+        sv1 = res if (sv_first is None or sv_first is res) else sv_first
+        el_first = timed_region(sv1, lambda k: sv1.iterate(k))[0]
+        del sv1
     del sv_first
     # SURVEY 8d config 4 is quoted on 10 fixed iterations: the same solver over kk = 0..9 (no full-Hessian storms yet)
     el10 = el if K == 10 else timed_region(res, lambda k: res.iterate(k), 10)[0]

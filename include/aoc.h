@@ -123,7 +123,9 @@ typedef struct aoc_params {
 } aoc_params;
 
 /* Scheduling knobs.  They select kernel variants and launch shapes only — results never depend on them
- * (tests/test_gpu_parity.py checks bit-identity across settings).  The defaults are read ONCE per process, at
+ * (tests/test_gpu_parity.py checks bit-identity across settings) — with ONE exception, the two *_hcut knobs at the end:
+ * the horizon cut evaluates the Riccati recursion in another order (gains equal to ~1e-14 of their scale; Armijo steps,
+ * trial counts and float32 states identical in every test, tests/test_gpu_hcut.py).  The defaults are read ONCE per process, at
  * the first call that needs them, from the environment variables named below; aoc_set_tuning() replaces them
  * (test hook / tuning tools), aoc_set_tuning(NULL) restores the defaults.  The settings are one plain process-wide
  * struct: aoc_set_tuning() must not run concurrently with any other call of this library.  (It MAY run between
@@ -151,7 +153,10 @@ typedef struct aoc_tuning {
     int32_t solve_repack_pct;  /* AOC_SOLVE_REPACK_PCT  aoc_newton_solve re-packs when at most this per cent of the batch in flight still iterates (70) */
     int32_t solve_sync_fast;   /* AOC_SOLVE_SYNC_FAST   ... and reads the count every this many iterations once trajectories have begun to stop (2) */
     int32_t solve_split_tiles; /* AOC_SOLVE_SPLIT_TILES aoc_newton_solve2 cuts batches of at least this many tiles in two halves on its two streams (2048) */
-    int32_t reserved;
+    int32_t track_hcut;        /* AOC_TRACK_HCUT        aoc_mpc_step: tracking gains with the HORIZON cut in this many segments that run in parallel
+                                  (k_track_hcut_*; 0 = never, -1 = 16 for batches of at most 64 tiles (-1)).  Unlike every other knob this one
+                                  changes the order of the arithmetic: gains agree with the sequential kernels to ~1e-14 of their scale */
+    int32_t bw_hcut;           /* AOC_BW_HCUT           the same for the Gauss-Newton backward pass of aoc_newton_iterate (k_bw_hcut) (-1) */
 } aoc_tuning;
 void aoc_get_tuning(aoc_tuning *out);
 void aoc_set_tuning(const aoc_tuning *t);

@@ -54,7 +54,7 @@ def test_geometry_helpers_and_errors():
     assert C.sizeof(_lib.Model) == 72
     assert C.sizeof(_lib.Problem) == 72 + 76 * 8 + 32 + 16
     assert C.sizeof(_lib.Params) == 48
-    assert C.sizeof(_lib.Tuning) == 76   # 19 int32: round 4 added solve_repack_pct / solve_sync_fast / solve_split_tiles
+    assert C.sizeof(_lib.Tuning) == 80   # 20 int32 (the last two: track_hcut, bw_hcut): round 4 added solve_repack_pct / solve_sync_fast / solve_split_tiles
     assert lib.aoc_abi_version() == _lib.AOC_ABI_VERSION == 4
     # argument errors are reported before anything touches a device
     p = _lib.Problem()

@@ -20,9 +20,14 @@ def _bench(tmp, gpus, per_gpu, steps=3, extra=("--cpu-budget-s", "1.5"), light=F
     env = dict(os.environ, AOC_BENCH_ONE_DEVICE="1", AOC_BENCH_BACKEND="gloo", AOC_BENCH_DUMP=str(d),
                AOC_BENCH_DUMP_LIGHT="1" if light else "0")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    try:    # what earlier tests of this process left in torch's cache is not available to the ranks otherwise
+        import torch
+        torch.cuda.empty_cache()
+    except Exception:
+        pass
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", str(steps),
                         "--warmup", "1", "--batch-per-gpu", str(per_gpu)] + list(extra), env=env,
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout

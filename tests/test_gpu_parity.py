@@ -372,12 +372,19 @@ def test_linesearch_rounds_vs_oracle(aoc, mode, tuned):
     assert len(seen) >= 4, "the sample should exercise several trial counts: %s" % sorted(seen)
 
 
-def test_shard_invariance_and_large_batch(aoc):
+@pytest.mark.parametrize("horizon_cut", [False, True])
+def test_shard_invariance_and_large_batch(aoc, tuned, horizon_cut):
     """8(e): results do not depend on the batch a trajectory is solved in.  Trajectories 0..639 of a
     66 000-trajectory launch (line-search rounds over >1000 wavefronts, one step per round) equal the
     same trajectories solved in a 640-trajectory launch (few wavefronts, many steps per round) bit
-    for bit; x0 is keyed by the global trajectory index."""
+    for bit; x0 is keyed by the global trajectory index.
+    horizon_cut (the default for batches of at most 64 tiles, aoc_tuning.bw_hcut): the Gauss-Newton backward pass of
+    the small launch evaluates the Riccati recursion in horizon segments — another order of the same arithmetic — so
+    there the comparison is: Armijo steps, trial counts and float32 states identical, costs and inputs equal to 1e-12
+    (measured 1e-14); with the cut switched off everything is bit for bit again."""
     from aircraftoptimalcontrol_amd import problems
+    if not horizon_cut:
+        tuned(bw_hcut=0, track_hcut=0)
     pr = problems.step_maneuver(1.0, 2e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
@@ -389,10 +396,19 @@ def test_shard_invariance_and_large_batch(aoc):
         out.append((h, s.current()))
     (hb, (xb, ub)), (hs, (xs, us)), (ht, (xt, ut)) = out
     for (h2, x2, u2, lo) in ((hs, xs, us, 0), (ht, xt, ut, 65000)):
-        assert np.array_equal(xb[lo:lo + 640], x2) and np.array_equal(ub[lo:lo + 640], u2)
+        assert np.array_equal(xb[lo:lo + 640], x2)
+        if horizon_cut:
+            ref = ub[lo:lo + 640]
+            assert (np.abs(ref - u2).max(2) / np.maximum(np.abs(ref).max(2), 1e-3)).max() < 1e-12
+            assert not np.array_equal(ref, u2), "the small launch is expected to take the horizon cut"
+        else:
+            assert np.array_equal(ub[lo:lo + 640], u2)
         for a, b in zip(hb, h2):
             for key in ("stepsize", "ntrials", "cost", "cost_new", "descent"):
-                assert np.array_equal(a[key][lo:lo + 640], b[key]), key
+                if horizon_cut and key in ("cost", "cost_new", "descent"):
+                    assert np.allclose(a[key][lo:lo + 640], b[key], rtol=1e-11, atol=0), key
+                else:
+                    assert np.array_equal(a[key][lo:lo + 640], b[key]), key
     # size-independent properties at scale: Armijo holds for every accepted step, costs decrease
     last = hb[-1]
     acc = last["ntrials"] < 10
@@ -627,12 +643,16 @@ def test_device_solve_on_two_streams_equals_one(aoc, tuned):
     for bp in (aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt),
                aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, XR, UR, pr.dt)):
         s = aoc.NewtonBatchSolver(bp, B, prm)
+        # (halves of 47 tiles would take the horizon cut in their Gauss-Newton iterations, the whole batch of 94 tiles
+        # would not — aoc_tuning.bw_hcut, not bit-identical —: off, as for every split the library makes by itself,
+        # whose halves have at least 1024 tiles)
+        tuned(bw_hcut=0)
         s.set_initial_from_x0(x0)
         one = s.solve_on_device(sync_every=2, two_streams=False)
-        tuned(solve_split_tiles=2)
+        tuned(solve_split_tiles=2, bw_hcut=0)
         s.set_initial_from_x0(x0)
         two, rows = _solve_trace(aoc, s, sync_every=2, two_streams=True)
-        tuned()
+        tuned(bw_hcut=0)
         assert sorted(set(rows[:, 0].astype(int))) == [0, 1]
         assert rows[rows[:, 0] == 0, 2].max() == 47 * 64 and rows[rows[:, 0] == 1, 2].max() == B - 47 * 64
         assert one["converged"].sum() > B // 2
