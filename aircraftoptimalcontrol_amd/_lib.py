@@ -85,7 +85,8 @@ SYMBOLS = {
     "aoc_traj_cost": (C.c_int, [_P, _P, _P, _P, _P]),
     "aoc_initial_trajectory": (C.c_int, [_P, _D, _D, _P, _P, _P]),
     "aoc_rollout_cost": (C.c_int, [_P] * 9),
-    "aoc_backward": (C.c_int, [_P, _I] + [_P] * 6),
+    "aoc_backward": (C.c_int, [_P, _I] + [_P] * 7 + [_Z]),
+    "aoc_backward_scratch_bytes": (_Z, [_I, _I]),
     "aoc_gradient": (C.c_int, [_P] * 7),
     "aoc_forward": (C.c_int, [_P, _P, _I] + [_P] * 9 + [_Z, _P]),
     "aoc_candidate_bytes": (_Z, [_I, _I, _I]),

@@ -360,8 +360,9 @@ class NewtonBatchSolver:
         st = torch.cuda.current_stream(self.problem.device)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record(st)
+        # (what lies behind K~ in the workspace is free until the forward pass: scratch of the backward pass, as in aoc_newton_iterate)
         check(lib().aoc_backward(C.byref(p), int(kk > prm.hessian_switch), _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
-                                 _ptr(Kt), None, _ptr(self.status)), "aoc_backward")
+                                 _ptr(Kt), None, _ptr(self.status), _ptr(du), (self.ws.numel() - Kt.numel()) * 8), "aoc_backward")
         ev[1].record(st)
         check(lib().aoc_forward(C.byref(p), C.byref(prm), nsp, _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
                                 _ptr(Kt), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status), _ptr(cand), cbytes,
@@ -850,7 +851,7 @@ def backward_forward(problem, xx, uu, full_hessian, stepsize_0=1.0, f32=False):
     x0t = pack_vec(xx[:, :, 0], dev)
     p = problem.c_problem(B, x_in_f32=int(f32))
     check(lib().aoc_backward(C.byref(p), int(bool(full_hessian)), _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt),
-                             _ptr(lm0), _ptr(st)), "aoc_backward")
+                             _ptr(lm0), _ptr(st), None, 0), "aoc_backward")
     prm = make_params(stepsize_0=stepsize_0)
     check(lib().aoc_forward(C.byref(p), C.byref(prm), 1, _ptr(xt), _ptr(ut), _ptr(x0t), _ptr(Kt), _ptr(du),
                             _ptr(desc), _ptr(Jn), _ptr(st), None, 0, None), "aoc_forward")

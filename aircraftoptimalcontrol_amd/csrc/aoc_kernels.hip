@@ -335,8 +335,13 @@ int aoc_rollout_cost(const aoc_problem* p, const double* x0, const double* u, co
     return aoc64::api_rollout_cost(p, x0, u, du, alpha, x_out, u_out, J_out, status);
 }
 int aoc_backward(const aoc_problem* p, int32_t full_hessian, const void* x, const double* u, const double* x0,
-                 double* Kt, double* lmbd0, int32_t* status) {
-    return aoc64::api_backward(p, full_hessian, x, u, x0, Kt, lmbd0, status);
+                 double* Kt, double* lmbd0, int32_t* status, void* scratch, size_t scratch_bytes) {
+    return aoc64::api_backward(p, full_hessian, x, u, x0, Kt, lmbd0, status, scratch, scratch_bytes);
+}
+size_t aoc_backward_scratch_bytes(int32_t B, int32_t T) {
+    (void)T;
+    const int S = B >= 1 ? aoc64::hcut_segments(tuning().bw_hcut, aoc_ntiles(B)) : 0;
+    return S >= 2 ? aoc64::hcut_scratch_bytes(aoc_ntiles(B), S) : 0;
 }
 int aoc_gradient(const aoc_problem* p, const void* x, const double* u, const double* x0, double* du, double* slope,
                  int32_t* status) {

@@ -94,8 +94,11 @@ def kernel_names(ntiles, full):
     small = ntiles <= t.split_tiles
     nspec = _lib.lib().aoc_default_nspec(ntiles * 64, 10)
     lin = t.fw_lin > 0 or (t.fw_lin < 0 and nspec <= 2)
+    hcut = (t.bw_hcut if t.bw_hcut >= 0 else (16 if ntiles <= 64 else 0)) if not full else 0
     return {
-        "backward": ("k_backward5<true, false, float>" if t.bw5 else "k_backward4<true, false, false, false, float>")
+        "backward": ("phase: k_bw_hcut<true, false, float, false> (segment maps), k_track_hcut_chain<true>, k_bw_hcut<true, false, float, true> "
+                     "(gains): the horizon in %d segments" % hcut) if hcut >= 2 and ntiles * hcut <= 1024 else
+                    ("k_backward5<true, false, float>" if t.bw5 else "k_backward4<true, false, false, false, float>")
                     if (not full and ntiles <= min(t.bw4_tiles, t.split_bw_tiles)) else
                     ("k_backward2<%s, float>" if ntiles <= t.split_bw_tiles else "k_backward<%s, float>") % fl,
         # <diagonal, shared reference, 2 speculated trials, states re-computed (the iterates of the run are rollouts), float32 states>

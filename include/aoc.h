@@ -51,8 +51,10 @@ extern "C" {
  * aoc_abi_version() returns the value the library was built with; a binding compares it with the header (or the
  * constant) it was written against and refuses to run on a mismatch instead of passing shifted arguments.
  *   3: round 3 (scratch_bytes / cand_bytes on the pass-level entries; aoc_workspace_bytes(B,T) covers exactly B)
- *   4: aoc_tuning + solve_repack_pct / solve_sync_fast / solve_split_tiles; aoc_newton_solve2, aoc_summary,
- *      aoc_solve_trace, aoc_abi_version; aoc_solve_workspace_bytes includes a fourth iterate buffer */
+ *   4: aoc_tuning + solve_repack_pct / solve_sync_fast / solve_split_tiles / track_hcut / bw_hcut; aoc_newton_solve2,
+ *      aoc_summary, aoc_solve_trace, aoc_abi_version, aoc_backward_scratch_bytes; aoc_backward takes a scratch region;
+ *      aoc_solve_workspace_bytes includes a fourth iterate buffer; aoc_default_nspec counts the step of an exhausted
+ *      search (armijo_maxiters + 1 where every candidate rides along) */
 #define AOC_ABI_VERSION 4
 
 #define AOC_TILE 64
@@ -221,9 +223,13 @@ int aoc_rollout_cost(const aoc_problem *prob, const double *x0, const double *u,
  * column side by side (one 16-byte access per column and lane):
  * Kt: [ntiles][T][7][64][2] doubles, elem(b,t,p,row) at ((((b/64)*T + t)*7 + p)*64 + b%64)*2 + row — the size of a
  * tiled C=14 array, aoc_tiled_elems(B,T,14); sample T-1 unused.
- * lmbd0 (optional, [ntiles][6][64]) receives lambda_0 (forces the costate sweep). */
+ * lmbd0 (optional, [ntiles][6][64]) receives lambda_0 (forces the costate sweep).
+ * scratch (may be NULL): device memory of scratch_bytes bytes that lets a Gauss-Newton pass of a batch of at most 64 tiles
+ * run with the horizon cut in parallel segments (aoc_tuning.bw_hcut; aoc_backward_scratch_bytes(B, T) says how much it
+ * takes; aoc_newton_iterate lends the part of its workspace behind K~).  Without it the sequential kernels run. */
+size_t aoc_backward_scratch_bytes(int32_t B, int32_t T);
 int aoc_backward(const aoc_problem *prob, int32_t full_hessian, const void *x, const double *u,
-                 const double *x0, double *Kt, double *lmbd0, int32_t *status);
+                 const double *x0, double *Kt, double *lmbd0, int32_t *status, void *scratch, size_t scratch_bytes);
 
 /* Descent direction of GradientMethod.optimize (optcon.py:101-123): the costate sweep lambda_t = A^T lambda_{t+1} + l_x
  * from lambda_{T-1} = grad l_T and du_t = -(B_t^T lambda_{t+1} + l_u); du tiled C=2 (sample T-1 zero).
