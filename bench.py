@@ -49,6 +49,17 @@ BYTES = {"backward": (176, 152), "forward": (192, 168), "linesearch_update": (96
 ITERATION_BYTES = 496   # whole Newton iteration (its formulation also carries g = B^T lambda + r)
 
 
+def provenance():
+    """What produced this line: the command line, and fingerprints of bench.py and of the library that was loaded (the
+    GPU box gets a snapshot without .git, so a commit hash is not available there)."""
+    import hashlib
+    from aircraftoptimalcontrol_amd import _lib
+    sha = lambda path: hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    return {"argv": sys.argv[1:], "bench_py_sha16": sha(os.path.abspath(__file__)), "lib_sha16": sha(_lib.library_path()),
+            "aoc_version": _lib.lib().aoc_version().decode(), "abi": int(_lib.lib().aoc_abi_version()),
+            "env": {k: v for k, v in os.environ.items() if k.startswith("AOC_")}}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -420,8 +431,9 @@ def run(a):
     fits = lambda: max(int((0.8 * free0 / share - (free0 - torch.cuda.mem_get_info(dev)[0]) / share) / per_solver), 1) if share > 1 \
         else max(int(0.8 * torch.cuda.mem_get_info(dev)[0] / per_solver), 1)
     placement = {"candidates": ncand if big else 1}
-    # one stream: the attribution pass, or everything with --no-overlap
-    n1 = (ncand if a.no_overlap else min(ncand, 3)) if big else 1
+    # one stream: the attribution pass (per-kernel durations behind `roofline` / `kernels`), or everything with --no-overlap;
+    # its allocation is chosen like the headline's (the write-heavy passes differ by 10-20 % between allocations)
+    n1 = ncand if big else 1
     s, placement["one_stream_solver"] = batch.best_placed(lambda: batch.NewtonBatchSolver(bp, Bg, prm), x0d, min(n1, fits()),
                                                           keep_first=a.no_overlap)
     # two half batches on two streams pay while each half is still a large-batch launch (one wavefront per tile kernels)
@@ -595,6 +607,7 @@ def run(a):
         "n_nonfinite": int(summ[4].item()),
         "value_finite_only": fin_b * K / el,
         "status_or_rank0": int(np.bitwise_or.reduce(sc["status"])),
+        "provenance": provenance(),
     }
     del s, s2, res
     torch.cuda.empty_cache()
