@@ -106,6 +106,7 @@ SYMBOLS = {
     "aoc_newton_solve2": (C.c_int, [_P] * 6 + [_Z, _I] + [_P] * 11),
     "aoc_abi_version": (_I, []),
     "aoc_summary": (C.c_int, [_I, _P, _P, _P, _P, _I, _P]),
+    "aoc_streams_concurrent": (C.c_int, [_P, _P]),
     "aoc_solve_trace": (C.c_int, [_P, _I]),
     "aoc_solve_trace_rows": (_I, []),
     "aoc_mpc_step": (C.c_int, [_P] * 3 + [_I] + [_P] * 6 + [_Z] + [_P] * 14),

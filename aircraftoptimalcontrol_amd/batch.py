@@ -215,14 +215,32 @@ class NewtonBatchSolver:
         dev = problem.device
         self.nt = ntiles(self.B)
         self.Bp = self.nt * TILE
-        self.xb = [alloc_tiled(B, self.T, 6, dev, zero=True, f32=True) for _ in range(3)]
-        self.ub = [alloc_tiled(B, self.T, 2, dev, zero=True) for _ in range(3)]
+        ws_elems = (lib().aoc_workspace_bytes(self.B, self.T) + 7) // 8
+        if os.environ.get("AOC_ARENA", "0") == "1":
+            # experiment (EXPERIMENTS.md round 4, placement): the iterate buffers and the workspace as views into ONE
+            # allocation, every piece on a 2 MiB boundary, instead of seven allocations
+            al = lambda nbytes: (nbytes + (1 << 21) - 1) >> 21 << 21
+            nx, nu = self.nt * self.T * 6 * TILE * 4, self.nt * self.T * 2 * TILE * 8
+            total = 3 * al(nx) + 3 * al(nu) + al(ws_elems * 8)
+            self._arena = torch.zeros(total, dtype=torch.uint8, device=dev)
+            off = [0]
+            def take(nbytes, dtype, shape):
+                v = self._arena[off[0]:off[0] + nbytes].view(dtype).view(shape)
+                off[0] += al(nbytes)
+                return v
+            self.xb = [take(nx, torch.float32, (self.nt, self.T, 6, TILE)) for _ in range(3)]
+            self.ub = [take(nu, torch.float64, (self.nt, self.T, 2, TILE)) for _ in range(3)]
+            self._ws_arena = take(ws_elems * 8, torch.float64, (ws_elems,))
+        else:
+            self.xb = [alloc_tiled(B, self.T, 6, dev, zero=True, f32=True) for _ in range(3)]
+            self.ub = [alloc_tiled(B, self.T, 2, dev, zero=True) for _ in range(3)]
+            self._ws_arena = None
         self.x64 = None            # fp64 copy of a caller-supplied initial iterate (only if needed)
         self.cur_is64 = False      # the current iterate is the one in self.x64
         self.cur_rollout = False   # the current iterate's states are the rollout of its inputs (written by the library)
         self.x_init = None         # (B,6,T) fp64: what set_initial() was given (returned verbatim if a
         self.u_init = None         #  trajectory stops at kk = 1, optcon.py:500-504)
-        self.ws = torch.empty((lib().aoc_workspace_bytes(self.B, self.T) + 7) // 8, dtype=torch.float64, device=dev)
+        self.ws = self._ws_arena if self._ws_arena is not None else torch.empty(ws_elems, dtype=torch.float64, device=dev)
         f = lambda: torch.zeros(self.Bp, dtype=torch.float64, device=dev)
         self.J = [f(), f()]
         self.descent, self.stepsize = f(), f()
@@ -585,8 +603,8 @@ class NewtonBatchSolver:
         hf = lambda dt: torch.empty((max(n_it, 1), self.Bp), dtype=dt, device=dev) if history else None
         hc, hd, hs, hn = hf(torch.float64), hf(torch.float64), hf(torch.float64), hf(torch.int32)
         n_run = C.c_int32(0)
-        if two_streams and getattr(self, "_stream2", None) is None:
-            self._stream2 = torch.cuda.Stream(device=dev)
+        if two_streams and getattr(self, "_stream2", None) is None:   # a stream that runs beside the current one
+            self._stream2 = concurrent_streams(dev, 2, first=torch.cuda.current_stream(dev))[1]
         st2 = C.c_void_p(self._stream2.cuda_stream) if two_streams else None
         torch.cuda.synchronize(dev)
         t_start = time.perf_counter()
@@ -649,6 +667,28 @@ class GradientBatchSolver(NewtonBatchSolver):
         raise NotImplementedError("aoc_newton_solve runs the Newton iteration; use solve()")
 
 
+def concurrent_streams(device, n=2, first=None, attempts=16):
+    """n HIP streams that really run side by side.  The runtime maps streams onto a few hardware queues (four by default)
+    and streams that share a queue take turns: of eight streams created one after the other {2, 3, 7}, {0, 5} and {1, 4}
+    shared one, and a two-stream solver on such a pair runs at one-stream speed (5.7 instead of 4.6-4.95 ms per
+    iteration: the "second candidate is always the slowest" of the placement probes of round 3 was this).  New streams
+    are created until n of them are pairwise concurrent (aoc_streams_concurrent: a 0.2 ms kernel on each).  `first`: a
+    stream that must be among them (e.g. the caller's current stream).  Falls back to what it has after `attempts`."""
+    torch = _torch()
+    dev = torch.device(device)
+    good = [first] if first is not None else []
+    spare = []
+    for _ in range(attempts):
+        if len(good) >= n:
+            break
+        st = torch.cuda.Stream(device=dev)
+        ok = all(lib().aoc_streams_concurrent(C.c_void_p(g.cuda_stream), C.c_void_p(st.cuda_stream)) == 1 for g in good)
+        (good if ok else spare).append(st)
+    while len(good) < n:      # not enough distinct queues: take what there is
+        good.append(spare.pop() if spare else torch.cuda.Stream(device=dev))
+    return good
+
+
 class TwoStreamNewtonSolver:
     """Fixed-iteration runs of a large batch as two half batches on two HIP streams, each a NewtonBatchSolver of its
     own: every kernel takes its stream from aoc_problem, so nothing in the library changes — the halves simply never
@@ -659,7 +699,7 @@ class TwoStreamNewtonSolver:
     in, so they equal those of one NewtonBatchSolver bit for bit.
     Interface: set_initial_from_x0 / iterate / run_fixed / join / scalars / current / summary_tensors."""
 
-    def __init__(self, problem, B, params=None):
+    def __init__(self, problem, B, params=None, streams=None):
         torch = _torch()
         nt = ntiles(B)
         if nt < 2:
@@ -668,7 +708,8 @@ class TwoStreamNewtonSolver:
         self.Ba = (nt // 2) * TILE
         self.parts = [NewtonBatchSolver(problem, self.Ba, params), NewtonBatchSolver(problem, self.B - self.Ba, params)]
         self.params = self.parts[0].params
-        self.streams = [torch.cuda.Stream(device=problem.device) for _ in self.parts]
+        # two streams on ONE hardware queue would take turns (concurrent_streams): checked once, here
+        self.streams = list(streams) if streams is not None else concurrent_streams(problem.device, len(self.parts))
         self.kk = 0
 
     def _on(self, fn):

@@ -107,6 +107,19 @@ __global__ __launch_bounds__(1024) void k_summary(int B, const double* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// Do two HIP streams run concurrently?  (aoc_streams_concurrent)  The runtime maps streams onto a few hardware queues
+// (four by default) and two streams on ONE queue take turns: a solver that cuts its batch in two halves on two such
+// streams runs at one-stream speed (measured: 5.7 instead of 4.6-4.95 ms per iteration; of eight streams created one after
+// the other, {2, 3, 7}, {0, 5} and {1, 4} shared a queue).  One wavefront per stream waits on the constant-rate clock.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_spin(long long ticks, int* sink) {
+    const long long t0 = wall_clock64();
+    int n = 0;
+    while (wall_clock64() - t0 < ticks && n < (1 << 24)) n++;   // bounded: every wave reaches the end
+    if (sink && n < 0) *sink = n;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side common to both arithmetic types
 // ---------------------------------------------------------------------------------------------
 static thread_local char g_hip_err[256] = "";
@@ -416,6 +429,38 @@ int aoc_summary(int32_t B, const double* cost, const double* descent, const int3
     if (B < 1 || !cost || !descent || !ntrials || !out5) return einval("aoc_summary: NULL argument or B < 1");
     hipLaunchKernelGGL(k_summary, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, cost, descent, ntrials, out5, accumulate);
     return check_launch("k_summary");
+}
+
+int aoc_streams_concurrent(void* stream_a, void* stream_b) {
+    hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
+    if (a == b) return 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess)
+        return check_launch("aoc_streams_concurrent");
+    int verdict = 0;
+    const long long ticks = 20000;   // 100 MHz constant clock: ~0.2 ms per kernel (the verdict is relative to ONE kernel's time)
+    for (int rep = 0; rep < 2; rep++) {   // the first repetition also pays for loading the code object
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) break;
+        float alone = 0.f, ta = 0.f, tb = 0.f;
+        (void)hipEventRecord(e0, a);                      // one kernel by itself
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks, (int*)nullptr);
+        (void)hipEventRecord(e1, a);
+        if (hipEventSynchronize(e1) != hipSuccess) break;
+        (void)hipEventElapsedTime(&alone, e0, e1);
+        (void)hipEventRecord(e0, a);                      // one on each stream
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks, (int*)nullptr);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks, (int*)nullptr);
+        (void)hipEventRecord(e1, a);
+        (void)hipEventRecord(e2, b);
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventSynchronize(e2) != hipSuccess) break;
+        (void)hipEventElapsedTime(&ta, e0, e1);
+        (void)hipEventElapsedTime(&tb, e0, e2);
+        const float span = ta > tb ? ta : tb;      // both kernels done, from the start of the first
+        verdict = span < 1.6f * alone ? 1 : 0;     // side by side: ~1x, one after the other: ~2x
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    const int rc = check_launch("aoc_streams_concurrent");
+    return rc ? rc : verdict;
 }
 
 int aoc_solve_trace(double* rows, int32_t cap_rows) {

@@ -52,7 +52,7 @@ extern "C" {
  * constant) it was written against and refuses to run on a mismatch instead of passing shifted arguments.
  *   3: round 3 (scratch_bytes / cand_bytes on the pass-level entries; aoc_workspace_bytes(B,T) covers exactly B)
  *   4: aoc_tuning + solve_repack_pct / solve_sync_fast / solve_split_tiles / track_hcut / bw_hcut; aoc_newton_solve2,
- *      aoc_summary, aoc_solve_trace, aoc_abi_version, aoc_backward_scratch_bytes; aoc_backward takes a scratch region;
+ *      aoc_summary, aoc_solve_trace, aoc_abi_version, aoc_backward_scratch_bytes, aoc_streams_concurrent; aoc_backward takes a scratch region;
  *      aoc_solve_workspace_bytes includes a fourth iterate buffer; aoc_default_nspec counts the step of an exhausted
  *      search (armijo_maxiters + 1 where every candidate rides along) */
 #define AOC_ABI_VERSION 4
@@ -406,6 +406,12 @@ int aoc_newton_solve2(const aoc_problem *prob, const aoc_params *prm, const void
                       const double *x0, void *workspace, size_t workspace_bytes, int32_t sync_every, void *x_star, double *u_star,
                       int32_t *iters, int32_t *ret_index, int32_t *status, double *hist_cost,
                       double *hist_descent, double *hist_stepsize, int32_t *hist_ntrials, int32_t *n_run, void *stream2);
+
+/* Do two HIP streams run side by side?  The runtime maps streams onto a few hardware queues (four by default) and two
+ * streams on one queue take turns — a caller who cuts a batch in two halves on two such streams (aoc_newton_solve2, or two
+ * solvers of its own) gets one-stream speed.  Runs one 0.2 ms single-wavefront kernel on each and compares the span:
+ * 1 = concurrent, 0 = they share a queue (or are the same stream), < 0 = AOC_E*.  Blocking (synchronises both streams). */
+int aoc_streams_concurrent(void *stream_a, void *stream_b);
 
 /* Diagnostic (no reference counterpart): timeline of the aoc_newton_solve calls that follow.  rows: HOST memory for
  * cap_rows rows of 6 doubles — part (0, or 1 = the half on stream2), iteration kk, trajectories in flight in that

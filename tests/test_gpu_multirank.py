@@ -117,6 +117,31 @@ def test_two_rank_rehearsal_with_placement_candidates_at_the_per_gpu_size(tmp_pa
     json.dump(two, open(out, "w"), indent=1)
 
 
+def test_streams_of_a_two_stream_solver_run_side_by_side():
+    """The runtime maps HIP streams onto a few hardware queues and two streams on one queue take turns (of eight streams
+    created in a row, five pairs shared a queue on this pool; a two-stream solver on such a pair ran at one-stream speed:
+    the always-slow second candidate of round 3's placement probes).  aoc_streams_concurrent tells, batch.concurrent_streams
+    makes sure: a stream is not concurrent with itself, the streams handed out are pairwise concurrent, and so are those
+    of a TwoStreamNewtonSolver — also of the fourth one built in a process."""
+    import ctypes as C
+    import torch
+    from aircraftoptimalcontrol_amd import batch as aoc, problems
+    from aircraftoptimalcontrol_amd._lib import lib
+    conc = lambda a, b: lib().aoc_streams_concurrent(C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream))
+    s = torch.cuda.Stream()
+    assert conc(s, s) == 0
+    three = aoc.concurrent_streams("cuda:0", 3)
+    assert len(three) == 3 and all(conc(a, b) == 1 for i, a in enumerate(three) for b in three[i + 1:])
+    cur = torch.cuda.current_stream()
+    pair = aoc.concurrent_streams("cuda:0", 2, first=cur)
+    assert pair[0] is cur and conc(pair[0], pair[1]) == 1
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    for _ in range(4):
+        t = aoc.TwoStreamNewtonSolver(bp, 256, aoc.make_params(stepsize_0=1.0, armijo_maxiters=10))
+        assert conc(*t.streams) == 1
+
+
 def test_two_stream_solver_equals_one_stream():
     """batch.TwoStreamNewtonSolver (two half batches on two HIP streams that never wait for each other — what
     bench.py times) against one NewtonBatchSolver: iterates, steps, trial counts and costs bit for bit, across the
