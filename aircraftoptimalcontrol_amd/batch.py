@@ -215,32 +215,14 @@ class NewtonBatchSolver:
         dev = problem.device
         self.nt = ntiles(self.B)
         self.Bp = self.nt * TILE
-        ws_elems = (lib().aoc_workspace_bytes(self.B, self.T) + 7) // 8
-        if os.environ.get("AOC_ARENA", "0") == "1":
-            # experiment (EXPERIMENTS.md round 4, placement): the iterate buffers and the workspace as views into ONE
-            # allocation, every piece on a 2 MiB boundary, instead of seven allocations
-            al = lambda nbytes: (nbytes + (1 << 21) - 1) >> 21 << 21
-            nx, nu = self.nt * self.T * 6 * TILE * 4, self.nt * self.T * 2 * TILE * 8
-            total = 3 * al(nx) + 3 * al(nu) + al(ws_elems * 8)
-            self._arena = torch.zeros(total, dtype=torch.uint8, device=dev)
-            off = [0]
-            def take(nbytes, dtype, shape):
-                v = self._arena[off[0]:off[0] + nbytes].view(dtype).view(shape)
-                off[0] += al(nbytes)
-                return v
-            self.xb = [take(nx, torch.float32, (self.nt, self.T, 6, TILE)) for _ in range(3)]
-            self.ub = [take(nu, torch.float64, (self.nt, self.T, 2, TILE)) for _ in range(3)]
-            self._ws_arena = take(ws_elems * 8, torch.float64, (ws_elems,))
-        else:
-            self.xb = [alloc_tiled(B, self.T, 6, dev, zero=True, f32=True) for _ in range(3)]
-            self.ub = [alloc_tiled(B, self.T, 2, dev, zero=True) for _ in range(3)]
-            self._ws_arena = None
+        self.xb = [alloc_tiled(B, self.T, 6, dev, zero=True, f32=True) for _ in range(3)]
+        self.ub = [alloc_tiled(B, self.T, 2, dev, zero=True) for _ in range(3)]
         self.x64 = None            # fp64 copy of a caller-supplied initial iterate (only if needed)
         self.cur_is64 = False      # the current iterate is the one in self.x64
         self.cur_rollout = False   # the current iterate's states are the rollout of its inputs (written by the library)
         self.x_init = None         # (B,6,T) fp64: what set_initial() was given (returned verbatim if a
         self.u_init = None         #  trajectory stops at kk = 1, optcon.py:500-504)
-        self.ws = self._ws_arena if self._ws_arena is not None else torch.empty(ws_elems, dtype=torch.float64, device=dev)
+        self.ws = torch.empty((lib().aoc_workspace_bytes(self.B, self.T) + 7) // 8, dtype=torch.float64, device=dev)
         f = lambda: torch.zeros(self.Bp, dtype=torch.float64, device=dev)
         self.J = [f(), f()]
         self.descent, self.stepsize = f(), f()

@@ -1,6 +1,8 @@
-"""Placement, one more experiment: does a solver whose big buffers are views into ONE allocation (AOC_ARENA=1) escape the
-spread of the seven-allocations solver?  N two-stream solvers built one after the other in one process, six-iteration probe
-and a 20-iteration run on each.   AOC_ARENA=0|1 python tools/arena_lottery.py [N=6]"""
+"""Placement or streams?  N two-stream solvers built one after the other in one process, six-iteration probe and a
+20-iteration run on each; AOC_SHARED_STREAMS=1: all of them on the same two streams (the always-slow second solver
+disappears: its own two streams shared a hardware queue, EXPERIMENTS.md round 4).  (The run recorded there with
+AOC_ARENA=1 — every solver's big buffers as views into ONE allocation — used a branch of batch.py that was removed again:
+same pattern as with seven allocations.)     [AOC_SHARED_STREAMS=1] python tools/arena_lottery.py [N=6]"""
 import os
 import sys
 import time
