@@ -3,8 +3,8 @@
 OUT=gpurun_out/tail_trace
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python tools/converge_timeline.py 4096 > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
-python - $OUT/trace <<'PY'
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python tools/converge_timeline.py ${1:-4096} > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
+python - $OUT/trace <<PY
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "aoc64::" in r["Kernel_Name"] or "k_s" in r["Kernel_Name"]]
@@ -13,8 +13,8 @@ short = lambda n: n.split("(")[0].replace("void ", "").replace("aoc64::", "").sp
 # iterations = from one backward kernel to the next; print iterations 5, 12, 25, 30 of the LAST solve in the trace
 starts = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith(("k_backward", "k_bw_hcut")) and (i == 0 or not short(rows[i-1]["Kernel_Name"]).startswith(("k_bw_hcut", "k_track_hcut")))]
 its = [rows[a:b] for a, b in zip(starts, starts[1:] + [len(rows)])]
-last = its[-37:]
-for n in (3, 12, 18, 25, 32):
+last = its[-int('${2:-37}'):]
+for n in (${3:-3, 12, 18, 25, 32}):
     if n >= len(last): continue
     it = last[n]
     t0 = int(it[0]["Start_Timestamp"])
