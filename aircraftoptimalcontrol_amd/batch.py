@@ -758,7 +758,7 @@ class TwoStreamNewtonSolver:
         return self.parts[1].summary(out, accumulate=True)
 
 
-def best_placed(make_solver, x0, candidates=5, probe_iters=6, keep_first=False):
+def best_placed(make_solver, x0, candidates=5, probe_iters=6, keep_first=False, force=None):
     """Allocation autotuning for large fixed-iteration runs: build `candidates` solvers (make_solver() -> a
     NewtonBatchSolver or TwoStreamNewtonSolver, each with allocations of its own), time Newton iterations
     kk = 0..probe_iters-1 from x0 (B,6) on each, keep the fastest and free the others.
@@ -773,7 +773,7 @@ def best_placed(make_solver, x0, candidates=5, probe_iters=6, keep_first=False):
     Returns (solver, info) with info = {"ms_per_iteration": [...], "chosen": index, "probe_iterations", "probe_wall_s":
     what the choice cost}.  keep_first: candidate 0 — the allocation a caller who does not choose gets — stays alive
     too and is returned as info["first"] (the chosen solver itself when that is candidate 0), so that it can be timed on
-    the same workload."""
+    the same workload.  force (tests): take candidate `force % candidates` whatever the probe says."""
     torch = _torch()
     t_wall = time.perf_counter()
     if int(candidates) <= 1:          # nothing to choose from: no probe either
@@ -800,7 +800,7 @@ def best_placed(make_solver, x0, candidates=5, probe_iters=6, keep_first=False):
             best = dt if best is None else min(best, dt)
         cands.append(sv)
         ms.append(round(best, 3))
-    chosen = int(np.argmin(ms))
+    chosen = int(np.argmin(ms)) if force is None else int(force) % len(cands)
     keep, first = cands[chosen], cands[0]
     del cands, sv
     info = {"ms_per_iteration": ms, "chosen": chosen, "probe_iterations": probe_iters}

@@ -431,17 +431,24 @@ def run(a):
     fits = lambda: max(int((0.8 * free0 / share - (free0 - torch.cuda.mem_get_info(dev)[0]) / share) / per_solver), 1) if share > 1 \
         else max(int(0.8 * torch.cuda.mem_get_info(dev)[0] / per_solver), 1)
     placement = {"candidates": ncand if big else 1}
+    # test hook (the 2-rank rehearsal): rank r takes candidate r instead of the fastest, so that the ranks' choices DIFFER
+    # and every branch that depends on a rank's own choice is taken differently by the ranks
+    force = rank if os.environ.get("AOC_BENCH_FORCE_CHOICE", "0") == "1" else None
     # one stream: the attribution pass (per-kernel durations behind `roofline` / `kernels`), or everything with --no-overlap;
     # its allocation is chosen like the headline's (the write-heavy passes differ by 10-20 % between allocations)
     n1 = ncand if big else 1
     s, placement["one_stream_solver"] = batch.best_placed(lambda: batch.NewtonBatchSolver(bp, Bg, prm), x0d, min(n1, fits()),
-                                                          keep_first=a.no_overlap)
+                                                          keep_first=a.no_overlap, force=force)
     # two half batches on two streams pay while each half is still a large-batch launch (one wavefront per tile kernels)
     overlap = not a.no_overlap and s.nt >= 2048 and fits() >= 1 and torch.cuda.mem_get_info(dev)[0] / share > 1.1 * per_solver
+    if world > 1:   # the timed regions hold collectives: every rank must take the same arrangement (free memory is a
+        #             per-rank observation — ranks rehearsing on one device see each other's transient allocations)
+        flag = torch.tensor([1.0 if overlap else 0.0], dtype=torch.float64, device=dev)
+        overlap = bool(sharding.all_reduce(-flag, "max").item() == -1.0)     # min over the ranks
     s2 = None
     if overlap:
         s2, placement["two_stream_solver"] = batch.best_placed(lambda: batch.TwoStreamNewtonSolver(bp, Bg, prm), x0d,
-                                                               min(ncand, fits()), keep_first=True)
+                                                               min(ncand, fits()), keep_first=True, force=force)
     # the solver a caller who does not choose its allocation gets: candidate 0 of the kind that is timed
     sv_first = placement["two_stream_solver" if overlap else "one_stream_solver"].pop("first", None)
     placement["one_stream_solver"].pop("first", None)
@@ -474,13 +481,16 @@ def run(a):
     # touched inside the timed region), then reset: the timed region is exactly iterations 0..K-1 of the solve
     res = s2 if overlap else s
     warm = [s2, s] if overlap else [s]
-    if sv_first is not None and sv_first is not res:
-        warm.append(sv_first)
     for sv in warm:
         sv.set_initial_from_x0(x0d)
         for k in range(a.warmup):
             sv.iterate(k)
         summary(sv)
+    if sv_first is not None and sv_first is not res:   # this rank's first candidate is not the chosen one: warmed up WITHOUT
+        sv_first.set_initial_from_x0(x0d)               # the collective (whether a rank gets here depends on its own draw)
+        for k in range(a.warmup):
+            sv_first.iterate(k)
+        sv_first.summary()
     s.iterate_timed(0)
     if overlap:
         el, every, summ, _ = timed_region(s2, lambda k: s2.iterate(k))

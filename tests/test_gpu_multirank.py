@@ -14,11 +14,11 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _bench(tmp, gpus, per_gpu, steps=3, extra=("--cpu-budget-s", "1.5"), light=False):
+def _bench(tmp, gpus, per_gpu, steps=3, extra=("--cpu-budget-s", "1.5"), light=False, force_choice=False):
     d = tmp / ("n%d_%d" % (gpus, per_gpu))
     d.mkdir()
     env = dict(os.environ, AOC_BENCH_ONE_DEVICE="1", AOC_BENCH_BACKEND="gloo", AOC_BENCH_DUMP=str(d),
-               AOC_BENCH_DUMP_LIGHT="1" if light else "0")
+               AOC_BENCH_DUMP_LIGHT="1" if light else "0", AOC_BENCH_FORCE_CHOICE="1" if force_choice else "0")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     try:    # what earlier tests of this process left in torch's cache is not available to the ranks otherwise
         import torch
@@ -99,17 +99,20 @@ def test_two_rank_rehearsal_with_placement_candidates_at_the_per_gpu_size(tmp_pa
     """The code path eight ranks take on an 8-GPU node, executed once on the one-GPU box: two ranks of
     131 072 trajectories each (--global-batch 262144: the north-star shard size), every rank choosing its allocation among
     candidates within ITS share of the free memory (fits()), two half batches on two streams, the first-allocated solver
-    timed beside the chosen one, every rank's draw gathered into the line, teardown, rank 0 finishing the record."""
+    timed beside the chosen one, every rank's draw gathered into the line, teardown, rank 0 finishing the record.  The
+    ranks are MADE to choose differently (rank r takes candidate r): twice a branch that depended on a rank's own choice or
+    on its own view of the free memory sat around a collective and hung two ranks that chose differently (round 4)."""
     G = 2 * 131072
     two, parts = _bench(tmp_path, 2, 0, steps=3, extra=("--global-batch", str(G), "--placement-candidates", "2",
-                                                        "--no-cpu-baseline", "--no-secondary"), light=True)
+                                                        "--no-cpu-baseline", "--no-secondary"), light=True, force_choice=True)
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["batch_per_gpu"] == 131072
     assert "two half batches" in two["config"]["streams"]
     pt = two["placement_tuning"]
     assert pt["candidates"] == 2 and len(pt["two_stream_solver"]["ms_per_iteration"]) == 2
     assert pt["two_stream_solver"]["probe_wall_s"] > 0
     draws = np.array(pt["per_rank_probe_ms_chosen_first"])
-    assert draws.shape == (2, 2) and (draws > 0).all() and (draws[:, 0] <= draws[:, 1]).all()   # chosen <= first, on every rank
+    assert draws.shape == (2, 2) and (draws > 0).all()
+    assert pt["two_stream_solver"]["chosen"] == 0 and draws[0, 0] == draws[0, 1] and draws[1, 0] != draws[1, 1]   # rank 0 took its first candidate, rank 1 its second
     assert two["ms_per_step_first_allocated"] > 0 and two["value_first_allocated"] > 0
     assert two["collective"]["world_seen"] == 2 and [int(p["first"]) for p in parts] == [0, 131072]
     assert parts[0]["cost"].shape[0] == 131072 and np.array_equal(parts[0]["summary"], parts[1]["summary"])
