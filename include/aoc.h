@@ -360,26 +360,34 @@ size_t aoc_solve_workspace_bytes(int32_t B, int32_t T);
 
 /* The reference's outer loop kk = 0 .. max_iters-2 with its per-trajectory stopping rule, run on the
  * device without returning to the host between iterations:
- *   - cost of the initial iterate (optcon.py:417-424), then aoc_newton_iterate per kk for the WHOLE batch
- *     (a stopped trajectory keeps riding along in its tile; its results are frozen);
+ *   - cost of the initial iterate (optcon.py:417-424), then aoc_newton_iterate per kk for the batch in flight: a stopped
+ *     trajectory keeps riding along in its tile with its results frozen until (sync_every > 0) the still-iterating ones
+ *     are re-packed into a dense smaller batch (aoc_tuning.solve_repack_pct; never with per-trajectory reference curves);
  *   - a trajectory stops at the first kk with descent[kk] >= prm->term_cond (optcon.py:499, Q6; a NaN
  *     descent never stops) and returns iterate kk-1 (optcon.py:500-504, Q7): ret_index[b] = kk-1, where -1
  *     means the reference's all-zero last history slot and 0 the initial iterate;
- *   - a trajectory that never stops returns the last computed iterate, ret_index[b] = iterations run;
+ *   - a trajectory that never stops returns the last computed iterate, ret_index[b] = max_iters-1.  A DIVERGED trajectory
+ *     never stops either (NaN >= term_cond is False, as in the reference): once every input sample of its iterate is NaN
+ *     nothing changes any more, and after one more iteration has run on that iterate it is retired with exactly what the
+ *     remaining iterations would produce (iterate, ret_index = iters = max_iters-1, status, history rows);
  *   - u_star[:, T-1] = u_star[:, T-2] (optcon.py:505, Q8).
  * (x_init, u_init): initial iterate, x_init of element type prob->x_in_f32, never written.  x0: fp64
  * [ntiles][6][64], xx_init[:,0] of every trajectory (optcon.py:398).
  * x_star (element type prob->x_out_f32), u_star: the returned iterates, tiled.  Sample 0 of x_star is the
  *   stored copy of x0 (rounded if float32): take it from x0.  For ret_index = 0 x_star/u_star hold the
- *   caller's initial iterate converted to the output type.
+ *   caller's initial iterate converted to the output type.  (The states of an iterate of index >= 1 are written at the END
+ *   of the call, as the rollout of its inputs — which they are, bit for bit: only the inputs are copied when a
+ *   trajectory stops.)
  * iters[b]: iterations the trajectory took part in; status[b]: flags raised up to its stopping iteration,
  *   AOC_ST_CONVERGED if it stopped by the descent test.
  * hist_* (each may be NULL): per-iteration scalars [max_iters-1][ntiles*64] — cost of the iterate the iteration
  *   started from, descent, accepted step, Armijo trials — NaN / -1 where the trajectory no longer iterated
  *   (rows beyond *n_run are not written).
- * sync_every: 0 = run all max_iters-1 iterations without any host synchronisation; n > 0 = every n
- *   iterations read back the number of trajectories still iterating (one blocking 4-byte copy) and stop
- *   launching when it is 0.  *n_run (host, may be NULL): iterations launched.
+ * sync_every: 0 = run all max_iters-1 iterations without any host synchronisation (and without re-packing); n > 0 = every n
+ *   iterations — every aoc_tuning.solve_sync_fast once trajectories have begun to stop — read back the number of
+ *   trajectories still iterating (one blocking 8-byte copy), stop launching when it is 0, re-pack when it is small.
+ *   *n_run (host, may be NULL): iterations the histories cover = iterations launched, or max_iters-1 when a diverged
+ *   trajectory was retired (its history rows run to the end).
  * workspace: aoc_solve_workspace_bytes(B,T) bytes of device memory. */
 int aoc_newton_solve(const aoc_problem *prob, const aoc_params *prm, const void *x_init, const double *u_init,
                      const double *x0, void *workspace, size_t workspace_bytes, int32_t sync_every, void *x_star, double *u_star,
