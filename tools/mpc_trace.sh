@@ -10,8 +10,8 @@ import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + '/trace/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 seq = [(r['Kernel_Name'].split('(')[0].replace('void ', '').replace('aoc64::', ''), int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows]
-# a step starts at k_track_gains2
-idx = [i for i, s in enumerate(seq) if s[0].startswith('k_track_gains')]
+# a step starts with the tracking gains (k_track_gains*, or k_track_hcut_map with the horizon cut)
+idx = [i for i, s in enumerate(seq) if s[0].startswith(('k_track_gains', 'k_track_hcut_map'))]
 steps = [seq[a:b] for a, b in zip(idx[:-1], idx[1:])]
 steps = steps[len(steps) // 2:]   # warm part
 agg = collections.OrderedDict(); gaps = 0.0; span = 0.0
