@@ -208,21 +208,31 @@ class NewtonBatchSolver:
     buffer and read from there by the first iteration.  `iterate(kk)` = one outer iteration for every
     trajectory; `solve()` adds the reference's termination and return-index behaviour per trajectory."""
 
-    def __init__(self, problem, B, params=None):
+    def __init__(self, problem, B, params=None, arena=None):
+        """arena (vmm.Arena, optional): where the big streams of the solver live — the three iterate buffers and the
+        K~/du workspace — instead of torch's allocator; `arena_layout` records what was taken.  The write-heavy streams
+        (workspace first, then the iterate buffers) each start on a physical handle of their own (new_handle)."""
         torch = _torch()
         self.problem, self.B, self.T = problem, int(B), problem.T
         self.params = params if params is not None else make_params()
         dev = problem.device
         self.nt = ntiles(self.B)
         self.Bp = self.nt * TILE
-        self.xb = [alloc_tiled(B, self.T, 6, dev, zero=True, f32=True) for _ in range(3)]
-        self.ub = [alloc_tiled(B, self.T, 2, dev, zero=True) for _ in range(3)]
+        self.arena = arena
+        ws_elems = (lib().aoc_workspace_bytes(self.B, self.T) + 7) // 8
+        if arena is not None:
+            self.ws = arena.take((ws_elems,), "float64", new_handle=True)
+            self.xb = [arena.take((self.nt, self.T, 6, TILE), "float32", zero=True, new_handle=True) for _ in range(3)]
+            self.ub = [arena.take((self.nt, self.T, 2, TILE), "float64", zero=True, new_handle=True) for _ in range(3)]
+        else:
+            self.xb = [alloc_tiled(B, self.T, 6, dev, zero=True, f32=True) for _ in range(3)]
+            self.ub = [alloc_tiled(B, self.T, 2, dev, zero=True) for _ in range(3)]
+            self.ws = torch.empty(ws_elems, dtype=torch.float64, device=dev)
         self.x64 = None            # fp64 copy of a caller-supplied initial iterate (only if needed)
         self.cur_is64 = False      # the current iterate is the one in self.x64
         self.cur_rollout = False   # the current iterate's states are the rollout of its inputs (written by the library)
         self.x_init = None         # (B,6,T) fp64: what set_initial() was given (returned verbatim if a
         self.u_init = None         #  trajectory stops at kk = 1, optcon.py:500-504)
-        self.ws = torch.empty((lib().aoc_workspace_bytes(self.B, self.T) + 7) // 8, dtype=torch.float64, device=dev)
         f = lambda: torch.zeros(self.Bp, dtype=torch.float64, device=dev)
         self.J = [f(), f()]
         self.descent, self.stepsize = f(), f()
@@ -614,6 +624,14 @@ class NewtonBatchSolver:
                     last_kk=n - 1, device_seconds=t_device)
 
 
+def solver_arena_bytes(B, T, gran=1 << 21, chunk=None):
+    """Bytes an arena must have for one NewtonBatchSolver(B, T) (seven buffers, each rounded up to a handle boundary)."""
+    a = chunk or gran
+    up = lambda v: (int(v) + a - 1) // a * a
+    nt = ntiles(B)
+    return (up(lib().aoc_workspace_bytes(B, T) + 8) + 3 * up(nt * T * 6 * TILE * 4) + 3 * up(nt * T * 2 * TILE * 8) + a)
+
+
 class GradientBatchSolver(NewtonBatchSolver):
     """B independent GradientMethod.optimize instances (reference optcon.py:27-174): steepest descent,
     du = -(B^T lambda + l_u) from the costate sweep (aoc_gradient), Armijo back-tracking and update through the same
@@ -681,14 +699,16 @@ class TwoStreamNewtonSolver:
     in, so they equal those of one NewtonBatchSolver bit for bit.
     Interface: set_initial_from_x0 / iterate / run_fixed / join / scalars / current / summary_tensors."""
 
-    def __init__(self, problem, B, params=None, streams=None):
+    def __init__(self, problem, B, params=None, streams=None, arenas=None):
         torch = _torch()
         nt = ntiles(B)
         if nt < 2:
             raise ValueError("a batch of one tile cannot be cut in two")
         self.problem, self.B, self.T = problem, int(B), problem.T
         self.Ba = (nt // 2) * TILE
-        self.parts = [NewtonBatchSolver(problem, self.Ba, params), NewtonBatchSolver(problem, self.B - self.Ba, params)]
+        ar = arenas if arenas is not None else (None, None)      # vmm.Arena per half (see NewtonBatchSolver)
+        self.parts = [NewtonBatchSolver(problem, self.Ba, params, arena=ar[0]),
+                      NewtonBatchSolver(problem, self.B - self.Ba, params, arena=ar[1])]
         self.params = self.parts[0].params
         # two streams on ONE hardware queue would take turns (concurrent_streams): checked once, here
         self.streams = list(streams) if streams is not None else concurrent_streams(problem.device, len(self.parts))

@@ -37,18 +37,65 @@ class Params(C.Structure):
 
 
 _lib = None
+_portable = None
+_SO_NATIVE = os.path.join(_HERE, "build", "liboracle_native.so")
+NATIVE_FLAGS = "-O3 -march=native -fno-tree-slp-vectorize -ffp-contract=off -fno-fast-math -fopenmp"
+PORTABLE_FLAGS = "-O2 -ffp-contract=off -fno-fast-math -fopenmp"
+flags = PORTABLE_FLAGS          # of the library lib() returns
+
+
+def _load(path):
+    l = C.CDLL(path)
+    l.orc_stagecost.restype = C.c_double
+    l.orc_termcost.restype = C.c_double
+    l.orc_traj_cost.restype = C.c_double
+    l.orc_armijo.restype = C.c_double
+    return l
 
 
 def lib():
-    global _lib
+    global _lib, _portable
     if _lib is None:
         build()
-        _lib = C.CDLL(_SO)
-        _lib.orc_stagecost.restype = C.c_double
-        _lib.orc_termcost.restype = C.c_double
-        _lib.orc_traj_cost.restype = C.c_double
-        _lib.orc_armijo.restype = C.c_double
+        _lib = _portable = _load(_SO)
     return _lib
+
+
+def use_native(on=True):
+    """Switch lib() to the build for THIS host (`make native`: -O3 -march=native, same floating-point rules) — what
+    bench.py's cpu_baseline times — or back to the portable -O2 build.  The native library is compiled here
+    and now (it cannot travel: the build container's CPU is not the GPU box's) and is accepted only if one Newton
+    iteration and a four-iteration chain on a few trajectories come out bit for bit as from the portable build.  Returns
+    the flags of the library now in use; raises if the native build cannot be made or differs."""
+    global _lib, flags
+    lib()
+    if not on:
+        _lib, flags = _portable, PORTABLE_FLAGS
+        return flags
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"])
+    nat = _load(_SO_NATIVE)
+    # self-check on synthetic inputs (no fixture needed): a smooth reference, perturbed starts
+    T, B = 120, 6
+    tt = np.linspace(0.0, 1.0, T)
+    xr = np.zeros((6, T)); xr[0] = 15.0 * tt; xr[1] = 1.0 / (1.0 + np.exp(-12 * (tt - 0.5))); xr[2] = 15.0
+    ur = np.zeros((2, T)); ur[0] = 46.0
+    Q = np.diag([1.0, 10.0, 0.1, 0.1, 0.1, 0.1]); R = np.diag([1e-3, 1e-2]); QT = 10 * Q
+    prob = OracleProblem(Q, R, QT, xr, ur, 1.0 / T)
+    prm = params()
+    rng = np.random.default_rng(7)
+    x0 = np.array([0.0, 0.0, 15.0, 0.05, 0.0, 0.02]) + rng.normal(0, 1, (B, 6)) * np.array([0.3, 0.3, 0.5, 0.02, 0.05, 0.02])
+    res = []
+    for l in (_portable, nat):
+        _lib = l
+        X, U = initial_guess_batch(prob.c.mdl, xr, x0, nthreads=2)
+        h = newton_iterate_batch(prob, prm, X, U, X[:, :, 0].copy(), 7, 4, nthreads=2)   # kk = 7..10: both Hessian regimes
+        res.append((X.copy(), U.copy(), h["cost"].copy(), h["descent"].copy(), h["stepsize"].copy(), h["ntrials"].copy()))
+    same = all(np.array_equal(a, b, equal_nan=True) for a, b in zip(*res))
+    if not same:
+        _lib, flags = _portable, PORTABLE_FLAGS
+        raise RuntimeError("the -march=native build of the oracle does not reproduce the portable build bit for bit")
+    _lib, flags = nat, NATIVE_FLAGS
+    return flags
 
 
 def _p(a):

@@ -13,7 +13,9 @@ import numpy as np
 from oracle import oracle as orc
 
 
-def sweep(aoc, problems, B=4096, n_it=12, dist="random", prob="step", seed=4242, log=None):
+def sweep(aoc, problems, B=4096, n_it=12, dist="random", prob="step", seed=4242, log=None, make_solver=None):
+    """make_solver(bp, B, prm) -> the solver under test (default: one NewtonBatchSolver; a TwoStreamNewtonSolver has the
+    same interface).  Which KERNELS it runs is decided by the batch size and aoc_tuning at the time of each iterate()."""
     # step maneuver at the bench's T = 500; the acrobatic problem at the reference's native T = 1000 (acrobatic_newton.py:72-76)
     pr = problems.step_maneuver(1.0, 2e-3) if prob == "step" else problems.acrobatic(1.0, 1e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
@@ -23,8 +25,9 @@ def sweep(aoc, problems, B=4096, n_it=12, dist="random", prob="step", seed=4242,
         x0[:, 2] = np.clip(x0[:, 2], 9.0, 12.0)
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
     oprm = orc.params(stepsize_0=1.0, armijo_maxiters=10)
-    s = aoc.NewtonBatchSolver(bp, B, prm)
+    s = (make_solver or aoc.NewtonBatchSolver)(bp, B, prm)
     s.set_initial_from_x0(x0)
+    parts = getattr(s, "parts", [s])      # a two-stream solver keeps one status array per half
     rows = []
     t_or = 0.0
     for kk in range(n_it):
@@ -46,7 +49,9 @@ def sweep(aoc, problems, B=4096, n_it=12, dist="random", prob="step", seed=4242,
         flagged = (sc["status"] & (4 | 8)) != 0       # singular / regularised gains in this iteration
         reg_g = (sc["status"] & 8) != 0               # GPU: M + 0.5 I applied at some stage of this iteration (optcon.py:745-749)
         reg_o = r["nreg"][:, 0] > 0                   # oracle: the same, counted per stage
-        s.status.zero_()
+        s.join()
+        for part in parts:
+            part.status.zero_()
         x_same = np.array([np.array_equal(xn[b], X[b], equal_nan=True) for b in range(B)])
         ok = step_eq & ntr_eq & fin                   # same Armijo verdicts: the iterates are comparable
         mx = lambda a, m: float(a[m].max()) if m.any() else 0.0
@@ -65,6 +70,10 @@ def sweep(aoc, problems, B=4096, n_it=12, dist="random", prob="step", seed=4242,
             nonfinite_set_difference=int(((np.isfinite(xn).all((1, 2)) & np.isfinite(un).all((1, 2))) !=
                                           (np.isfinite(X).all((1, 2)) & np.isfinite(U).all((1, 2)))).sum()),
             u_channel_rel_max=mx(chan, ok), u_channel_rel_max_unflagged=mx(chan, ok & ~flagged),
+            # where the gains were regularised the recursion is not contractive (Q3): the distribution, not only its worst case
+            u_channel_rel_p99_flagged=float(np.percentile(chan[ok & flagged], 99.0)) if (ok & flagged).any() else 0.0,
+            u_channel_rel_median_flagged=float(np.median(chan[ok & flagged])) if (ok & flagged).any() else 0.0,
+            n_flagged_over_1e3=int((chan[ok & flagged] > 1e-3).sum()),
             u_elementwise_rel_max_unflagged=mx(elem, ok & ~flagged), u_elementwise_rel_median=float(np.median(elem[ok])) if ok.any() else 0.0,
             u_elementwise_rel_p999=float(np.percentile(elem[ok], 99.9)) if ok.any() else 0.0,
             u_channel_rel_median=float(np.median(chan[ok])) if ok.any() else 0.0,
