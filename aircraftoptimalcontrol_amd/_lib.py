@@ -13,7 +13,7 @@ _SRC = [os.path.join(_PKG, "csrc", f) for f in ("aoc_kernels.hip", "aoc_device.h
 _HDR = os.path.join(os.path.dirname(_PKG), "include", "aoc.h")
 
 AOC_TILE = 64
-AOC_ABI_VERSION = 4   # include/aoc.h: the revision this binding (struct layouts, argument lists) is written against
+AOC_ABI_VERSION = 5   # include/aoc.h: the revision this binding (struct layouts, argument lists) is written against
 
 # status flags (include/aoc.h)
 ST_NAN, ST_VNONPOS, ST_SINGULAR, ST_REGULARISED, ST_ARMIJO_EXH, ST_CONVERGED = 1, 2, 4, 8, 16, 32
@@ -56,6 +56,11 @@ class Params(C.Structure):
     _fields_ = [("max_iters", C.c_int32), ("armijo_maxiters", C.c_int32), ("stepsize_0", C.c_double),
                 ("cc", C.c_double), ("beta", C.c_double), ("term_cond", C.c_double),
                 ("hessian_switch", C.c_int32), ("reserved", C.c_int32)]
+
+
+class MpcNoise(C.Structure):
+    """aoc_mpc_noise (include/aoc.h): the disturbance model aoc_mpc_step draws on the device."""
+    _fields_ = [("seed", C.c_uint64), ("step", C.c_uint32), ("first", C.c_uint32), ("sigma", C.c_double * 6)]
 
 
 class Tuning(C.Structure):
@@ -109,7 +114,7 @@ SYMBOLS = {
     "aoc_streams_concurrent": (C.c_int, [_P, _P]),
     "aoc_solve_trace": (C.c_int, [_P, _I]),
     "aoc_solve_trace_rows": (_I, []),
-    "aoc_mpc_step": (C.c_int, [_P] * 3 + [_I] + [_P] * 6 + [_Z] + [_P] * 14),
+    "aoc_mpc_step": (C.c_int, [_P] * 3 + [_I] + [_P] * 6 + [_Z] + [_P] * 16),
     "aoc_traj_cost_f32": (C.c_int, [_P] * 5),
     "aoc_initial_trajectory_f32": (C.c_int, [_P, _D, _D, _P, _P, _P]),
     "aoc_rollout_cost_f32": (C.c_int, [_P] * 9),

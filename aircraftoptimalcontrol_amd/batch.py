@@ -595,9 +595,13 @@ class NewtonBatchSolver:
         hf = lambda dt: torch.empty((max(n_it, 1), self.Bp), dtype=dt, device=dev) if history else None
         hc, hd, hs, hn = hf(torch.float64), hf(torch.float64), hf(torch.float64), hf(torch.int32)
         n_run = C.c_int32(0)
-        if two_streams and getattr(self, "_stream2", None) is None:   # a stream that runs beside the current one
-            self._stream2 = concurrent_streams(dev, 2, first=torch.cuda.current_stream(dev))[1]
-        st2 = C.c_void_p(self._stream2.cuda_stream) if two_streams else None
+        st2 = None
+        if two_streams:   # a stream that runs beside the CURRENT one (the pairing is checked once per current stream)
+            cur = torch.cuda.current_stream(dev)
+            pairs = self.__dict__.setdefault("_stream2_for", {})
+            if cur.cuda_stream not in pairs:
+                pairs[cur.cuda_stream] = concurrent_streams(dev, 2, first=cur)[1]
+            st2 = C.c_void_p(pairs[cur.cuda_stream].cuda_stream)
         torch.cuda.synchronize(dev)
         t_start = time.perf_counter()
         check(lib().aoc_newton_solve2(C.byref(p), C.byref(prm), _ptr(x), _ptr(self.ub[self.cur]), _ptr(self.x0), _ptr(ws), ws.numel() * 8,
@@ -678,14 +682,18 @@ def concurrent_streams(device, n=2, first=None, attempts=16):
     dev = torch.device(device)
     good = [first] if first is not None else []
     spare = []
-    for _ in range(attempts):
-        if len(good) >= n:
-            break
-        st = torch.cuda.Stream(device=dev)
-        ok = all(lib().aoc_streams_concurrent(C.c_void_p(g.cuda_stream), C.c_void_p(st.cuda_stream)) == 1 for g in good)
-        (good if ok else spare).append(st)
-    while len(good) < n:      # not enough distinct queues: take what there is
-        good.append(spare.pop() if spare else torch.cuda.Stream(device=dev))
+    with torch.cuda.device(dev):      # the probe's events are created on the current device: the streams' device
+        for _ in range(attempts):
+            if len(good) >= n:
+                break
+            st = torch.cuda.Stream(device=dev)
+            verdicts = [lib().aoc_streams_concurrent(C.c_void_p(g.cuda_stream), C.c_void_p(st.cuda_stream)) for g in good]
+            for v in verdicts:
+                if v < 0:
+                    check(v, "aoc_streams_concurrent")
+            (good if all(v == 1 for v in verdicts) else spare).append(st)
+        while len(good) < n:      # not enough distinct queues: take what there is
+            good.append(spare.pop() if spare else torch.cuda.Stream(device=dev))
     return good
 
 

@@ -555,4 +555,51 @@ __device__ __forceinline__ StageFlags lqr_stage(const KConst& k, const Lin& l, r
 }
 
 #undef SYM
+
+// ---------------------------------------------------------------------------------------------
+// Disturbance model of the receding-horizon plant step, drawn on the device (the reference's closed loop,
+// lqr_tracking.py:279-281, has none: this is the build's own, BASELINE configs[4] "small seeded disturbance").
+// Counter-based: Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11) with key = seed and
+// counter = (global instance index, closed-loop step, pair index j, 0) — no state, so the draw of (instance, step) does
+// not depend on the shard an instance lives in nor on what was drawn before.  One counter gives four 32-bit words = two
+// 53-bit uniforms u1, u2 in (0, 1] = two standard normals by Box-Muller, sqrt(-2 ln u1) (cos, sin)(2 pi u2); three
+// counters per instance and step give the six components, component c scaled by sigma[c].
+// Always evaluated in fp64 (once per instance and step: no throughput matters here).
+// ---------------------------------------------------------------------------------------------
+struct MpcNoise {
+    unsigned key0, key1;     // seed (low, high word)
+    unsigned step, first;    // closed-loop step; global index of instance 0 of this batch
+    double sigma[6];
+    int on;
+};
+
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// the six disturbance components of global instance `inst` at the step of `nz`
+__device__ __forceinline__ void mpc_noise_draw(const MpcNoise& nz, unsigned inst, double d[6]) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        unsigned w[4];
+        philox4x32_10(inst, nz.step, (unsigned)j, 0u, nz.key0, nz.key1, w);
+        // 53-bit uniforms in (0, 1]: (27 high bits of one word, 26 of the next) + 1, times 2^-53
+        const double u1 = ((double)(w[0] >> 5) * 67108864.0 + (double)(w[1] >> 6) + 1.0) * 0x1.0p-53;
+        const double u2 = ((double)(w[2] >> 5) * 67108864.0 + (double)(w[3] >> 6) + 1.0) * 0x1.0p-53;
+        const double rad = sqrt(-2.0 * log(u1));
+        double sn, cs;
+        sincos(6.283185307179586476925 * u2, &sn, &cs);
+        d[2 * j] = nz.sigma[2 * j] * (rad * cs);
+        d[2 * j + 1] = nz.sigma[2 * j + 1] * (rad * sn);
+    }
+}
 }  // namespace AOC_ARITH_NS

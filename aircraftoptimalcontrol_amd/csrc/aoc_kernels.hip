@@ -231,7 +231,7 @@ constexpr int AOC_SPEC_MAX = 15;   // Armijo candidates that may ride along in t
 
 extern "C" {
 
-const char* aoc_version(void) { return "aoc-hip 0.4 (gfx950)"; }
+const char* aoc_version(void) { return "aoc-hip 0.5 (gfx950)"; }
 int32_t aoc_abi_version(void) { return AOC_ABI_VERSION; }
 
 const char* aoc_strerror(int code) {
@@ -434,33 +434,37 @@ int aoc_summary(int32_t B, const double* cost, const double* descent, const int3
 int aoc_streams_concurrent(void* stream_a, void* stream_b) {
     hipStream_t a = (hipStream_t)stream_a, b = (hipStream_t)stream_b;
     if (a == b) return 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess)
-        return check_launch("aoc_streams_concurrent");
-    int verdict = 0;
+    (void)hipGetLastError();   // an older sticky error is not this call's result
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    auto destroy = [&] { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
+    for (int i = 0; i < 3; i++)
+        if (hipEventCreate(&ev[i]) != hipSuccess) { destroy(); return check_launch("aoc_streams_concurrent") ? AOC_ELAUNCH : AOC_ELAUNCH; }
+    hipEvent_t e0 = ev[0], e1 = ev[1], e2 = ev[2];
+    int verdict = AOC_ELAUNCH;     // until a repetition has run to its end
     const long long ticks = 20000;   // 100 MHz constant clock: ~0.2 ms per kernel (the verdict is relative to ONE kernel's time)
+    // (the events live on the CURRENT device: the caller selects the device the streams belong to — batch.concurrent_streams
+    // does — and a record on a stream of another device fails here instead of leaving the elapsed times at zero)
     for (int rep = 0; rep < 2; rep++) {   // the first repetition also pays for loading the code object
         if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) break;
         float alone = 0.f, ta = 0.f, tb = 0.f;
-        (void)hipEventRecord(e0, a);                      // one kernel by itself
+        if (hipEventRecord(e0, a) != hipSuccess) break;        // one kernel by itself
         hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks, (int*)nullptr);
-        (void)hipEventRecord(e1, a);
-        if (hipEventSynchronize(e1) != hipSuccess) break;
-        (void)hipEventElapsedTime(&alone, e0, e1);
-        (void)hipEventRecord(e0, a);                      // one on each stream
+        if (hipEventRecord(e1, a) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) break;
+        if (hipEventElapsedTime(&alone, e0, e1) != hipSuccess) break;
+        if (hipEventRecord(e0, a) != hipSuccess) break;        // one on each stream
         hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks, (int*)nullptr);
         hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks, (int*)nullptr);
-        (void)hipEventRecord(e1, a);
-        (void)hipEventRecord(e2, b);
+        if (hipEventRecord(e1, a) != hipSuccess || hipEventRecord(e2, b) != hipSuccess) break;
         if (hipEventSynchronize(e1) != hipSuccess || hipEventSynchronize(e2) != hipSuccess) break;
-        (void)hipEventElapsedTime(&ta, e0, e1);
-        (void)hipEventElapsedTime(&tb, e0, e2);
+        if (hipEventElapsedTime(&ta, e0, e1) != hipSuccess || hipEventElapsedTime(&tb, e0, e2) != hipSuccess) break;
         const float span = ta > tb ? ta : tb;      // both kernels done, from the start of the first
         verdict = span < 1.6f * alone ? 1 : 0;     // side by side: ~1x, one after the other: ~2x
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    destroy();
     const int rc = check_launch("aoc_streams_concurrent");
-    return rc ? rc : verdict;
+    if (rc) return rc;
+    if (verdict < 0) snprintf(g_hip_err, sizeof g_hip_err, "aoc_streams_concurrent: an event record / elapsed-time query failed (streams of another device than the current one?)");
+    return verdict;
 }
 
 int aoc_solve_trace(double* rows, int32_t cap_rows) {
@@ -475,9 +479,10 @@ int aoc_mpc_step(const aoc_problem* p_track, const aoc_problem* p_next, const ao
                  const void* x_cur, const double* u_cur, double* x0, double* x_true, const double* disturbance,
                  void* workspace, size_t workspace_bytes, double* Kgain, void* x_a, double* u_a, void* x_b, double* u_b,
                  double* J_a, double* J_b, double* descent, double* stepsize, int32_t* ntrials, int32_t* status, double* K0,
-                 double* u_applied, int32_t* final_slot) {
+                 double* u_applied, int32_t* final_slot, const aoc_mpc_noise* noise, double* disturbance_out) {
     return aoc64::api_mpc_step(p_track, p_next, prm, n_newton, x_cur, u_cur, x0, x_true, disturbance, workspace, workspace_bytes, Kgain, x_a,
-                               u_a, x_b, u_b, J_a, J_b, descent, stepsize, ntrials, status, K0, u_applied, final_slot);
+                               u_a, x_b, u_b, J_a, J_b, descent, stepsize, ntrials, status, K0, u_applied, final_slot, noise,
+                               disturbance_out);
 }
 
 // ---- float32 arithmetic (aoc32): every array, the reference curves and the workspace are float32 ------

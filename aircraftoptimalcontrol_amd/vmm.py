@@ -18,9 +18,20 @@ _HIP = None
 
 
 def _hip():
+    """The HIP runtime that is ALREADY mapped in this process (torch's): two runtimes in one process do not share
+    devices or allocations (see _lib.lib()), so the library is opened by the path /proc/self/maps shows."""
     global _HIP
     if _HIP is None:
-        _HIP = C.CDLL("libamdhip64.so")
+        import torch  # noqa: F401  (maps its libamdhip64)
+        path = None
+        try:
+            for line in open("/proc/self/maps"):
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        except OSError:
+            pass
+        _HIP = C.CDLL(path or "libamdhip64.so")
     return _HIP
 
 
@@ -82,13 +93,15 @@ class Arena:
     buffer's size when it is full).  take(shape, dtype) carves tensors off the front.  The mapping lives as long as the
     arena object; tensors taken from it must not outlive it."""
 
-    def __init__(self, device, nbytes, chunk_bytes=None, recommended=True, align=None):
+    def __init__(self, device, nbytes, chunk_bytes=None, recommended=True, align=None, min_granule=2 << 20):
         import torch
         self.device = torch.device(device)
         self.index = self.device.index or 0
         torch.cuda.set_device(self.device)
         h = _hip()
-        self.gran = granularity(self.index, recommended)
+        # the runtime reports 4 KiB on MI355X (ROCm 7.2), but a mapping that does not start on a 2 MiB boundary is refused
+        # by hipMemSetAccess (invalid argument, measured): handles and offsets are kept to multiples of `min_granule`
+        self.gran = max(granularity(self.index, recommended), int(min_granule))
         self._up = lambda v, a: (int(v) + a - 1) // a * a
         self.chunk = self._up(chunk_bytes, self.gran) if chunk_bytes else None
         self.size = self._up(nbytes, self.chunk or self.gran)

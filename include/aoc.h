@@ -54,8 +54,11 @@ extern "C" {
  *   4: aoc_tuning + solve_repack_pct / solve_sync_fast / solve_split_tiles / track_hcut / bw_hcut; aoc_newton_solve2,
  *      aoc_summary, aoc_solve_trace, aoc_abi_version, aoc_backward_scratch_bytes, aoc_streams_concurrent; aoc_backward takes a scratch region;
  *      aoc_solve_workspace_bytes includes a fourth iterate buffer; aoc_default_nspec counts the step of an exhausted
- *      search (armijo_maxiters + 1 where every candidate rides along) */
-#define AOC_ABI_VERSION 4
+ *      search (armijo_maxiters + 1 where every candidate rides along)
+ *   5: aoc_mpc_step takes aoc_mpc_noise (the disturbance drawn on the device) and disturbance_out; the horizon cut is
+ *      decided once per aoc_newton_solve from the caller's batch (a trajectory's bits no longer depend on the generation or
+ *      half it is solved in) */
+#define AOC_ABI_VERSION 5
 
 #define AOC_TILE 64
 #define AOC_NS 6
@@ -444,12 +447,25 @@ int32_t aoc_solve_trace_rows(void);
  * State arrays are float32 (prob->x_in_f32 = x_out_f32 = 1).  (x_a,u_a,J_a) and (x_b,u_b,J_b): two iterate
  * buffers distinct from (x_cur,u_cur); *final_slot (host) = 0 / 1: which of them holds the new optimum and
  * its cost.  x0, x_true, disturbance (may be NULL), K0 ([ntiles][12][64], may be NULL), u_applied
- * ([ntiles][2][64]): per-instance vectors laid out like x0.  workspace: aoc_workspace_bytes(B,T). */
+ * ([ntiles][2][64]): per-instance vectors laid out like x0.  workspace: aoc_workspace_bytes(B,T).
+ * The disturbance of step 2 is  disturbance[b] (caller's array, may be NULL)  +  the draw of the device's own model when
+ * `noise` (HOST pointer, may be NULL) is given: component c of instance b gets sigma[c] * z, z standard normal from the
+ * counter-based generator Philox4x32-10 with key = seed and counter = (first + b, step, c / 2, 0), two normals per counter by
+ * Box-Muller (csrc/aoc_device.h: mpc_noise_draw) — a function of (seed, global instance index, step) alone: no state
+ * between calls, the same draws whatever the sharding, no host round trip.  disturbance_out (DEVICE, [ntiles][6][64], may
+ * be NULL) receives what was added, for a checker. */
+typedef struct aoc_mpc_noise {
+    uint64_t seed;
+    uint32_t step;      /* closed-loop step index of this call */
+    uint32_t first;     /* global index of instance 0 of this batch (shard offset) */
+    double sigma[6];    /* standard deviation per state component */
+} aoc_mpc_noise;
 int aoc_mpc_step(const aoc_problem *prob_track, const aoc_problem *prob_next, const aoc_params *prm,
                  int32_t n_newton, const void *x_cur, const double *u_cur, double *x0, double *x_true,
                  const double *disturbance, void *workspace, size_t workspace_bytes, double *Kgain, void *x_a, double *u_a, void *x_b,
                  double *u_b, double *J_a, double *J_b, double *descent, double *stepsize, int32_t *ntrials,
-                 int32_t *status, double *K0, double *u_applied, int32_t *final_slot);
+                 int32_t *status, double *K0, double *u_applied, int32_t *final_slot, const aoc_mpc_noise *noise,
+                 double *disturbance_out);
 
 /* ---------------------------------------------------------------------------------------------
  * float32 arithmetic (BASELINE.json configs[2]: "fp32 with tolerance sweep").

@@ -55,7 +55,8 @@ def test_geometry_helpers_and_errors():
     assert C.sizeof(_lib.Problem) == 72 + 76 * 8 + 32 + 16
     assert C.sizeof(_lib.Params) == 48
     assert C.sizeof(_lib.Tuning) == 80   # 20 int32 (the last two: track_hcut, bw_hcut): round 4 added solve_repack_pct / solve_sync_fast / solve_split_tiles
-    assert lib.aoc_abi_version() == _lib.AOC_ABI_VERSION == 4
+    assert C.sizeof(_lib.MpcNoise) == 64  # uint64 seed, two uint32, six doubles (ABI revision 5)
+    assert lib.aoc_abi_version() == _lib.AOC_ABI_VERSION == 5
     # argument errors are reported before anything touches a device
     p = _lib.Problem()
     assert lib.aoc_traj_cost(C.byref(p), None, None, None, None) == -1

@@ -49,7 +49,9 @@ def test_receding_horizon_vs_oracle(tuned, large_batch_kernels):
     x_true = x0.copy()
     for s in range(n_steps):
         out = rh.step()
-        dist = rh.disturbance(s)
+        dist = rh.last_disturbance()                    # the device's own draws, read back (the oracle is fed the same numbers)
+        want = rh.disturbance(s)                        # ... and the host restatement of the generator: the checker of the draws
+        assert np.abs(dist - want).max() <= 1e-13 * sigma.max() and np.abs(dist).max() > 0, (s, np.abs(dist - want).max())
         op = oprob(s + 1)
         for b in range(B):
             _, _, KK, ns = orc.lqr_tracking(mdl, tw[0], tw[1], tw[2], XX[b], UU[b], np.zeros(6))
@@ -71,6 +73,44 @@ def test_receding_horizon_vs_oracle(tuned, large_batch_kernels):
         for b in range(B):
             assert np.array_equal(xg[b], XX[b]), (s, b)
             assert rel_err(ug[b], UU[b], 1e-3) < 1e-8, (s, b)
+
+
+def test_device_noise_model(tuned):
+    """The disturbance aoc_mpc_step draws on the device (aoc_mpc_noise): (i) equal to the NumPy restatement
+    of the generator (Philox4x32-10 by its published known-answer vectors in tests/test_host_logic.py, Box-Muller) to 1e-13
+    of sigma for every instance and step, by both plant-step kernels (the fused small-batch launch and the three-launch
+    path); (ii) a function of the GLOBAL instance index: a shard starting at instance 70 draws what instances 70.. of the
+    whole fleet draw; (iii) standard normal: mean, variance and cross-correlation over 130 x 6 x 12 draws; (iv) the loop
+    with the draws uploaded from the host (noise="host") reaches the same plant states."""
+    from aircraftoptimalcontrol_amd import mpc, problems
+    T, n_steps, B = 100, 12, 130
+    pr = _mpc_problem(T, n_steps)
+    tw = problems.tracking_weights()
+    sigma = np.array([0.02, 0.03, 0.01, 0.002, 0.004, 0.003])
+    x0 = problems.perturbed_x0(pr, B, seed=2)
+    runs = {}
+    for name, kw, knobs in (("device", dict(), {}), ("device_large", dict(), dict(split_tiles=0, split_bw_tiles=0, nspec=2)),
+                            ("host", dict(noise="host"), {}), ("shard", dict(first=70), {})):
+        tuned(**knobs)
+        n = B - 70 if name == "shard" else B
+        rh = mpc.RecedingHorizon(pr, tw, n, T, n_newton=1, sigma=sigma, seed=(5 << 32) + 99, horizon_steps=32, **kw)
+        rh.start(x0[70:] if name == "shard" else x0, cold_iters=3)
+        draws, states = [], []
+        for s in range(n_steps):
+            out = rh.step()
+            draws.append(rh.last_disturbance()); states.append(out["x_true"].copy())
+            assert np.abs(draws[-1] - rh.disturbance(s)).max() <= 1e-13 * sigma.max(), (name, s)
+        runs[name] = (np.array(draws), np.array(states))
+    d = runs["device"][0]
+    assert np.array_equal(d, runs["device_large"][0]) and np.array_equal(runs["device"][1], runs["device_large"][1])
+    assert np.array_equal(d[:, 70:], runs["shard"][0]) and np.array_equal(runs["device"][1][:, 70:], runs["shard"][1])
+    z = d / sigma
+    assert abs(z.mean()) < 4.0 / np.sqrt(z.size) and abs(z.std() - 1.0) < 0.05
+    assert np.abs(np.corrcoef(z.reshape(-1, 6).T) - np.eye(6)).max() < 0.15
+    assert len(np.unique(z)) == z.size                                  # no instance, step or component repeats a draw
+    # uploaded draws: the same numbers to 1e-13 of sigma, the same plant states up to float32 rounding ties
+    flips = int((runs["host"][1] != runs["device"][1]).any(2).sum())
+    assert flips <= 2 and np.abs(runs["host"][1] - runs["device"][1]).max() < 1e-5, flips
 
 
 def _mpc_problem(T, steps):
@@ -107,7 +147,8 @@ def test_receding_horizon_three_tiles_twenty_resolves_vs_oracle():
     for s in range(n_steps):
         out = rh.step()
         assert rh.s == s + 1
-        dist = rh.disturbance(s)
+        dist = rh.last_disturbance()
+        assert np.abs(dist - rh.disturbance(s)).max() <= 1e-13 * sigma.max()
         op = oprob(s + 1)
         xg, ug = rh.solver.current()
         for b in range(B):

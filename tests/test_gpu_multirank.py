@@ -112,7 +112,9 @@ def test_two_rank_rehearsal_with_placement_candidates_at_the_per_gpu_size(tmp_pa
     assert pt["two_stream_solver"]["probe_wall_s"] > 0
     draws = np.array(pt["per_rank_probe_ms_chosen_first"])
     assert draws.shape == (2, 2) and (draws > 0).all()
-    assert pt["two_stream_solver"]["chosen"] == 0 and draws[0, 0] == draws[0, 1] and draws[1, 0] != draws[1, 1]   # rank 0 took its first candidate, rank 1 its second
+    # rank 0 took its first candidate, rank 1 its second (the choice itself is checked, not two rounded timings that may coincide)
+    assert pt["two_stream_solver"]["chosen"] == 0 and draws[0, 0] == draws[0, 1]
+    assert pt["per_rank_chosen"] == [0, 1]
     assert two["ms_per_step_first_allocated"] > 0 and two["value_first_allocated"] > 0
     assert two["collective"]["world_seen"] == 2 and [int(p["first"]) for p in parts] == [0, 131072]
     assert parts[0]["cost"].shape[0] == 131072 and np.array_equal(parts[0]["summary"], parts[1]["summary"])

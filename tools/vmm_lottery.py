@@ -54,7 +54,7 @@ def main():
                 sv = batch.NewtonBatchSolver(bp, B, prm)
             else:
                 chunk = None if mode == "one" else int(mode[1:]) << 20
-                need = batch.solver_arena_bytes(B, T, gran=vmm.granularity(0, rec), chunk=chunk)
+                need = batch.solver_arena_bytes(B, T, gran=max(vmm.granularity(0, rec), 2 << 20), chunk=chunk)
                 ar = vmm.Arena(dev, need, chunk_bytes=chunk, recommended=rec)
                 sv = batch.NewtonBatchSolver(bp, B, prm, arena=ar)
             keep.append(sv)
