@@ -68,7 +68,8 @@ class Tuning(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("nspec", "split_tiles", "split_bw_tiles", "fw_lin", "ls_wcap", "ls_kgrow",
                                          "trial_split", "solve_norepack", "ls_worklist", "ls_cpl", "ls_depth_min",
                                          "fw_recompute", "store_candidates", "bw4_tiles", "bw5", "solve_repack_pct",
-                                         "solve_sync_fast", "solve_split_tiles", "track_hcut", "bw_hcut")]
+                                         "solve_sync_fast", "solve_split_tiles", "track_hcut", "bw_hcut", "fw_wpe1",
+                                         "reserved")]
 
 
 # every symbol include/aoc.h declares: (name, restype, argtypes)

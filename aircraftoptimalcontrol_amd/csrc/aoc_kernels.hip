@@ -38,6 +38,11 @@ using aoc_common::TILE;
     } while (0)
 #define AOC_DISPATCH_DR(kc, NAME_D, NAME_R, ...) \
     AOC_DISPATCH_BOOL((kc).diag, NAME_D, AOC_DISPATCH_RPT((kc).rpt, NAME_R, __VA_ARGS__))
+#define AOC_DISPATCH_WPE(one, NAME, ...)              \
+    do {                                              \
+        if (one) { constexpr int NAME = 1; __VA_ARGS__; } \
+        else { constexpr int NAME = 2; __VA_ARGS__; }     \
+    } while (0)
 #define AOC_DISPATCH_XT(f32, NAME, ...)               \
     do {                                              \
         if (f32) { using NAME = float; __VA_ARGS__; } \
@@ -171,6 +176,7 @@ static void tuning_defaults(aoc_tuning* t) {
     t->solve_split_tiles = env("AOC_SOLVE_SPLIT_TILES", 2048);
     t->track_hcut = env("AOC_TRACK_HCUT", -1);
     t->bw_hcut = env("AOC_BW_HCUT", -1);
+    t->fw_wpe1 = env("AOC_FW_WPE1", 1);
 }
 
 static const aoc_tuning& tuning() {

@@ -87,75 +87,89 @@ _TYPESTR = {"float64": "<f8", "float32": "<f4", "int32": "<i4", "uint8": "|u1"}
 
 
 class Arena:
-    """A reserved virtual range of `nbytes` on `device`, backed by physical handles as it is used: handles of `chunk_bytes`
-    each (rounded up to the granularity), or — chunk_bytes None — one handle per take(new_handle=True), sized for that
-    buffer (buffers taken without new_handle share the handle that is open, which grows by further handles of the
-    buffer's size when it is full).  take(shape, dtype) carves tensors off the front.  The mapping lives as long as the
-    arena object; tensors taken from it must not outlive it."""
+    """Device memory for the big streams of a solver, backed by physical handles the caller sizes.
+      chunk_bytes = None: every take(new_handle=True) gets a reservation and ONE physical handle of its own, sized for that
+                    buffer (takes without new_handle share the last one while it has room);
+      chunk_bytes = n:    one reservation of `nbytes`, aligned to n, backed by uniform handles of n bytes mapped as the
+                    arena is used (on this runtime a handle must sit at an offset that is a multiple of its size: 1.5 GiB +
+                    1 GiB in one range is refused, equal chunks work — tools/probes/vmm_probe2.py).
+    The mappings live as long as the arena object; tensors taken from it must not outlive it."""
 
-    def __init__(self, device, nbytes, chunk_bytes=None, recommended=True, align=None, min_granule=2 << 20):
+    def __init__(self, device, nbytes, chunk_bytes=None, recommended=True, min_granule=2 << 20):
         import torch
         self.device = torch.device(device)
         self.index = self.device.index or 0
         torch.cuda.set_device(self.device)
-        h = _hip()
-        # the runtime reports 4 KiB on MI355X (ROCm 7.2), but a mapping that does not start on a 2 MiB boundary is refused
-        # by hipMemSetAccess (invalid argument, measured): handles and offsets are kept to multiples of `min_granule`
+        # the runtime reports 4 KiB on MI355X (ROCm 7.2); handles and offsets are kept to multiples of `min_granule`
         self.gran = max(granularity(self.index, recommended), int(min_granule))
         self._up = lambda v, a: (int(v) + a - 1) // a * a
         self.chunk = self._up(chunk_bytes, self.gran) if chunk_bytes else None
         self.size = self._up(nbytes, self.chunk or self.gran)
-        self.base = C.c_void_p(0)
-        _check(h.hipMemAddressReserve(C.byref(self.base), C.c_size_t(self.size), C.c_size_t(int(align or 0)), None, C.c_ulonglong(0)),
-               "hipMemAddressReserve")
-        self.handles = []      # (handle, offset, bytes)
-        self.mapped = 0        # [0, mapped) is backed
-        self.used = 0
+        self.segments = []     # [base, reserved bytes, mapped bytes, used bytes, [(handle, offset, bytes)]]
+        if self.chunk:
+            self._reserve(self.size, self.chunk)
 
-    def _map(self, nbytes):
-        """one more physical handle of nbytes (a multiple of the granularity) at the end of what is mapped"""
+    def _reserve(self, nbytes, align):
+        base = C.c_void_p(0)
+        _check(_hip().hipMemAddressReserve(C.byref(base), C.c_size_t(nbytes), C.c_size_t(int(align)), None, C.c_ulonglong(0)),
+               "hipMemAddressReserve")
+        self.segments.append([base.value, nbytes, 0, 0, []])
+        return self.segments[-1]
+
+    def _map(self, seg, nbytes):
+        """one more physical handle of nbytes at the end of what is mapped in `seg`"""
         h = _hip()
-        if self.mapped + nbytes > self.size:
-            raise MemoryError("arena of %d bytes exhausted (%d mapped, %d more asked)" % (self.size, self.mapped, nbytes))
+        if seg[2] + nbytes > seg[1]:
+            raise MemoryError("arena segment of %d bytes exhausted (%d mapped, %d more asked)" % (seg[1], seg[2], nbytes))
         prop = _prop(self.index)
         hd = C.c_void_p(0)
-        at = C.c_void_p(self.base.value + self.mapped)
+        at = C.c_void_p(seg[0] + seg[2])
         _check(h.hipMemCreate(C.byref(hd), C.c_size_t(nbytes), C.byref(prop), C.c_ulonglong(0)), "hipMemCreate")
         _check(h.hipMemMap(at, C.c_size_t(nbytes), C.c_size_t(0), hd, C.c_ulonglong(0)), "hipMemMap")
         acc = _AccessDesc()
         acc.location.type, acc.location.id, acc.flags = 1, self.index, 3   # device, read-write
         _check(h.hipMemSetAccess(at, C.c_size_t(nbytes), C.byref(acc), C.c_size_t(1)), "hipMemSetAccess")
-        self.handles.append((hd, self.mapped, nbytes))
-        self.mapped += nbytes
+        seg[4].append((hd, seg[2], nbytes))
+        seg[2] += nbytes
+
+    @property
+    def handles(self):
+        return [hd for seg in self.segments for hd in seg[4]]
 
     def take(self, shape, dtype="float64", zero=False, new_handle=False):
         import torch
         name = str(dtype).replace("torch.", "")
         item = np.dtype(_TYPESTR[name]).itemsize
         n = int(np.prod(shape)) * item
-        start = self.mapped if new_handle else self._up(self.used, 256)
-        if start < self.used:
-            start = self._up(self.used, 256)
-        end = start + n
-        while self.mapped < end:
-            self._map(self.chunk if self.chunk else self._up(end - self.mapped, self.gran))
-        self.used = end
-        t = torch.as_tensor(_Raw(self.base.value + start, shape, _TYPESTR[name]), device=self.device)
+        if self.chunk:
+            seg = self.segments[0]
+            start = max(seg[2] if new_handle else 0, self._up(seg[3], 256))
+            while seg[2] < start + n:
+                self._map(seg, self.chunk)
+        else:
+            seg = self.segments[-1] if self.segments else None
+            start = self._up(seg[3], 256) if seg else 0
+            if new_handle or seg is None or start + n > seg[2]:
+                seg = self._reserve(self._up(n, self.gran), self.gran)
+                self._map(seg, seg[1])
+                start = 0
+        seg[3] = start + n
+        t = torch.as_tensor(_Raw(seg[0] + start, shape, _TYPESTR[name]), device=self.device)
         if zero:
             t.zero_()
         return t
 
     def close(self):
         h = _hip()
-        if self.base and self.base.value:
+        if self.segments:
             import torch
             torch.cuda.synchronize(self.device)
-            for hd, off, n in self.handles:
-                h.hipMemUnmap(C.c_void_p(self.base.value + off), C.c_size_t(n))
-                h.hipMemRelease(hd)
-            h.hipMemAddressFree(self.base, C.c_size_t(self.size))
-            self.base = C.c_void_p(0)
-            self.handles = []
+            for base, size, _, _, hds in self.segments:
+                for hd, off, n in hds:
+                    h.hipMemUnmap(C.c_void_p(base + off), C.c_size_t(n))
+                    h.hipMemRelease(hd)
+                h.hipMemAddressFree(C.c_void_p(base), C.c_size_t(size))
+            self.segments = []
 
     def __del__(self):
         try:

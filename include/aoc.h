@@ -57,7 +57,7 @@ extern "C" {
  *      search (armijo_maxiters + 1 where every candidate rides along)
  *   5: aoc_mpc_step takes aoc_mpc_noise (the disturbance drawn on the device) and disturbance_out; the horizon cut is
  *      decided once per aoc_newton_solve from the caller's batch (a trajectory's bits no longer depend on the generation or
- *      half it is solved in) */
+ *      half it is solved in); aoc_tuning.fw_wpe1 */
 #define AOC_ABI_VERSION 5
 
 #define AOC_TILE 64
@@ -162,6 +162,9 @@ typedef struct aoc_tuning {
                                   (k_track_hcut_*; 0 = never, -1 = 16 for batches of at most 64 tiles (-1)).  Unlike every other knob this one
                                   changes the order of the arithmetic: gains agree with the sequential kernels to ~1e-14 of their scale */
     int32_t bw_hcut;           /* AOC_BW_HCUT           the same for the Gauss-Newton backward pass of aoc_newton_iterate (k_bw_hcut) (-1) */
+    int32_t fw_wpe1;           /* AOC_FW_WPE1           small-batch forward pass: launches of at most one workgroup per CU run the build
+                                  compiled for one wavefront per SIMD (512 registers, nothing spilt) (1) */
+    int32_t reserved;
 } aoc_tuning;
 void aoc_get_tuning(aoc_tuning *out);
 void aoc_set_tuning(const aoc_tuning *t);

@@ -36,7 +36,7 @@ def test_geometry_helpers_and_errors():
     # a batch small enough to give every Armijo candidate a wavefront of its own (tiles x groups of three <= 256) keeps the
     # candidate trajectories: aoc_workspace_bytes(B) holds the largest store a batch of exactly B can ask for ...
     assert lib.aoc_workspace_bytes(64, 500) == base(64) + lib.aoc_candidate_bytes(64, 500, lib.aoc_spec_max())
-    assert lib.aoc_candidate_bytes(64, 500, 10) == 10 * (64 * 500 * 48 + 64 * 4) + 16   # records, flags, stored count per tile
+    assert lib.aoc_candidate_bytes(64, 500, 10) == 10 * (64 * 500 * 24 + 64 * 4) + 16   # records (float32 states: 24 B), flags, stored count per tile
     for B, m in ((4096, 12), (8192, 6), (5440, 9), (4096, 10), (3264, 15)):    # (tiles, candidates) at the edge of the rule
         assert lib.aoc_default_ncand(B, m, m) == m, (B, m)
         assert lib.aoc_workspace_bytes(B, 500) >= base(B) + lib.aoc_candidate_bytes(B, 500, m), (B, m)
@@ -47,14 +47,14 @@ def test_geometry_helpers_and_errors():
     # smaller generations in the workspace of the first (768 stored (tile, candidate) pairs at most)
     extra = max(lib.aoc_workspace_bytes(64 * t, 500) - base(64 * t) for t in range(1, 257))
     assert lib.aoc_solve_workspace_bytes(131072, 500) - lib.aoc_solve_workspace_bytes(131072, 500) % 256 >= base(131072) + extra - 256
-    assert 768 * (500 * 64 * 48 + 256) <= extra < 768 * (500 * 64 * 48 + 256) + 4096
+    assert 768 * (500 * 64 * 24 + 256) <= extra < 768 * (500 * 64 * 24 + 256) + 4096
     assert b"gfx950" in lib.aoc_version()
     assert lib.aoc_strerror(-1) == b"invalid argument"
     # struct layout must match the header: 9 doubles + 76 doubles + 8 int32 + 2 pointers
     assert C.sizeof(_lib.Model) == 72
     assert C.sizeof(_lib.Problem) == 72 + 76 * 8 + 32 + 16
     assert C.sizeof(_lib.Params) == 48
-    assert C.sizeof(_lib.Tuning) == 80   # 20 int32 (the last two: track_hcut, bw_hcut): round 4 added solve_repack_pct / solve_sync_fast / solve_split_tiles
+    assert C.sizeof(_lib.Tuning) == 88   # 22 int32 (round 5: fw_wpe1 + one reserved)
     assert C.sizeof(_lib.MpcNoise) == 64  # uint64 seed, two uint32, six doubles (ABI revision 5)
     assert lib.aoc_abi_version() == _lib.AOC_ABI_VERSION == 5
     # argument errors are reported before anything touches a device

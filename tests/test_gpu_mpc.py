@@ -108,9 +108,11 @@ def test_device_noise_model(tuned):
     assert abs(z.mean()) < 4.0 / np.sqrt(z.size) and abs(z.std() - 1.0) < 0.05
     assert np.abs(np.corrcoef(z.reshape(-1, 6).T) - np.eye(6)).max() < 0.15
     assert len(np.unique(z)) == z.size                                  # no instance, step or component repeats a draw
-    # uploaded draws: the same numbers to 1e-13 of sigma, the same plant states up to float32 rounding ties
-    flips = int((runs["host"][1] != runs["device"][1]).any(2).sum())
-    assert flips <= 2 and np.abs(runs["host"][1] - runs["device"][1]).max() < 1e-5, flips
+    # uploaded draws: the same numbers to 1e-13 of sigma (NumPy's log / sin / cos against the device's), hence the same plant
+    # states (float32-rounded step + the draw) to that level, up to float32 rounding ties of the step
+    dx = np.abs(runs["host"][1] - runs["device"][1])
+    flips = int((dx > 1e-12).any(2).sum())
+    assert flips <= 2 and dx.max() < 1e-5, (flips, dx.max())
 
 
 def _mpc_problem(T, steps):
