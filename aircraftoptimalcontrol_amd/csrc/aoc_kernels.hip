@@ -177,6 +177,8 @@ static void tuning_defaults(aoc_tuning* t) {
     t->track_hcut = env("AOC_TRACK_HCUT", -1);
     t->bw_hcut = env("AOC_BW_HCUT", -1);
     t->fw_wpe1 = env("AOC_FW_WPE1", 1);
+    t->hcut_chain6 = env("AOC_HCUT_CHAIN6", 0);
+    t->bw_hcut_full = env("AOC_BW_HCUT_FULL", 2);
 }
 
 static const aoc_tuning& tuning() {
@@ -360,7 +362,7 @@ int aoc_backward(const aoc_problem* p, int32_t full_hessian, const void* x, cons
 size_t aoc_backward_scratch_bytes(int32_t B, int32_t T) {
     (void)T;
     const int S = B >= 1 ? aoc64::hcut_segments(tuning().bw_hcut, aoc_ntiles(B)) : 0;
-    return S >= 2 ? aoc64::hcut_scratch_bytes(aoc_ntiles(B), S) : 0;
+    return S >= 2 ? aoc64::hcut_full_scratch_bytes(aoc_ntiles(B), S) : 0;   // (what a full-Hessian pass takes; Gauss-Newton: a part of it)
 }
 int aoc_gradient(const aoc_problem* p, const void* x, const double* u, const double* x0, double* du, double* slope,
                  int32_t* status) {

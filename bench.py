@@ -105,15 +105,21 @@ def kernel_names(ntiles, full):
     small = ntiles <= t.split_tiles
     nspec = _lib.lib().aoc_default_nspec(ntiles * 64, 10)
     lin = t.fw_lin > 0 or (t.fw_lin < 0 and nspec <= 2)
-    hcut = (t.bw_hcut if t.bw_hcut >= 0 else (16 if ntiles <= 64 else 0)) if not full else 0
+    hcut = (t.bw_hcut if t.bw_hcut >= 0 else (16 if ntiles <= 64 else 0)) if (not full or t.bw_hcut_full) else 0
+    chain = "k_hcut_chain6<true>" if t.hcut_chain6 else "k_track_hcut_chain<true>"
+    ngroups = -(-nspec // 3)
+    wpe = 1 if (t.fw_wpe1 and ntiles * ngroups <= 256) else 2
     return {
-        "backward": ("phase: k_bw_hcut<true, false, float, false> (segment maps), k_track_hcut_chain<true>, k_bw_hcut<true, false, float, true> "
-                     "(gains): the horizon in %d segments" % hcut) if hcut >= 2 and ntiles * hcut <= 1024 else
+        "backward": ("phase: " + ("k_bw_hcut_lam<true, false, float> (costate maps), " if full else "") +
+                     "k_bw_hcut<true, false, float, false%s> (segment maps), %s, k_bw_hcut<true, false, float, true%s> (gains)%s: the horizon in %d segments"
+                     % (", true" if full else "", chain, ", true" if full else "",
+                        ", k_backward2<true, false, true, true, float> (lanes with an indefinite M)" if full else "", hcut))
+                    if hcut >= 2 and ntiles * hcut <= 1024 else
                     ("k_backward5<true, false, float>" if t.bw5 else "k_backward4<true, false, false, false, float>")
                     if (not full and ntiles <= min(t.bw4_tiles, t.split_bw_tiles)) else
                     ("k_backward2<%s, float>" if ntiles <= t.split_bw_tiles else "k_backward<%s, float>") % fl,
         # <diagonal, shared reference, 2 speculated trials, states re-computed (the iterates of the run are rollouts), float32 states>
-        "forward": ("k_forward_lin<true, false, float>" if lin else "k_forward_split<true, false, float>") if small else
+        "forward": ("k_forward_lin<true, false, float, %d>" % wpe if lin else "k_forward_split<true, false, float, %d>" % wpe) if small else
                    "k_forward<true, false, 2, %s, float>" % ("true" if t.fw_recompute else "false"),
         "linesearch_update": "k_ls_final_split<true, false, float>" if small else "k_ls_final<true, false, float>",
         "linesearch_search": ("phase: k_ls_init_wl, k_ls_plan_wl, k_ls_trial_wl<true, false, %d, pinned|plain> x2, k_ls_replan" % max(t.ls_cpl, 1)) if wl

@@ -57,7 +57,7 @@ extern "C" {
  *      search (armijo_maxiters + 1 where every candidate rides along)
  *   5: aoc_mpc_step takes aoc_mpc_noise (the disturbance drawn on the device) and disturbance_out; the horizon cut is
  *      decided once per aoc_newton_solve from the caller's batch (a trajectory's bits no longer depend on the generation or
- *      half it is solved in); aoc_tuning.fw_wpe1 */
+ *      half it is solved in); aoc_tuning.fw_wpe1, hcut_chain6, bw_hcut_full */
 #define AOC_ABI_VERSION 5
 
 #define AOC_TILE 64
@@ -164,7 +164,12 @@ typedef struct aoc_tuning {
     int32_t bw_hcut;           /* AOC_BW_HCUT           the same for the Gauss-Newton backward pass of aoc_newton_iterate (k_bw_hcut) (-1) */
     int32_t fw_wpe1;           /* AOC_FW_WPE1           small-batch forward pass: launches of at most one workgroup per CU run the build
                                   compiled for one wavefront per SIMD (512 registers, nothing spilt) (1) */
-    int32_t reserved;
+    int32_t hcut_chain6;       /* AOC_HCUT_CHAIN6       horizon cut: the serial chain of boundary hops on four wavefronts per tile (three take two
+                                  columns of the dense 6x6 algebra each, one stages the next map through LDS: k_hcut_chain6; bit-identical
+                                  to the one-wavefront chain).  Measured SLOWER than one wavefront (102 vs 73 us), hence off (0) */
+    int32_t bw_hcut_full;      /* AOC_BW_HCUT_FULL      the horizon cut also for full-Hessian backward passes (costate maps first; tiles with an
+                                  indefinite or singular M anywhere are recomputed by the sequential kernel, bit-identical to an uncut pass; 2: only
+                                  those with a singular / ill-conditioned M or a value function that is not a number) (2) */
 } aoc_tuning;
 void aoc_get_tuning(aoc_tuning *out);
 void aoc_set_tuning(const aoc_tuning *t);
