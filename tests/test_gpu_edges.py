@@ -157,3 +157,38 @@ def test_nan_and_v_nonpositive_are_flagged_not_fatal(aoc):
     keep = np.ones(64, bool); keep[[7, 40]] = False
     assert not st[keep].any()
     assert np.array_equal(x_bad[keep], x_ok[keep]) and np.array_equal(u_bad[keep], u_ok[keep])
+
+
+@pytest.mark.parametrize("chunk_mb", [None, 64])
+def test_solver_on_a_vmm_arena_equals_the_solver_on_torch_memory(aoc, chunk_mb):
+    """vmm.Arena (HIP virtual-memory management: a reservation backed by physical handles of a stated size, handed out as
+    torch tensors) as the home of a solver's big streams: the same results bit for bit — where memory lives decides speed
+    (DESIGN.md section 4 "placement"), never values — and the arena's bookkeeping (one handle per stream / uniform chunks)."""
+    import torch
+    from aircraftoptimalcontrol_amd import problems, vmm
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    B = 200
+    x0 = problems.perturbed_x0(pr, B, seed=9)
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+    chunk = None if chunk_mb is None else chunk_mb << 20
+    ar = vmm.Arena(bp.device, aoc.solver_arena_bytes(B, pr.T, chunk=chunk), chunk_bytes=chunk)
+    res = []
+    for arena in (None, ar):
+        s = aoc.NewtonBatchSolver(bp, B, prm, arena=arena)
+        s.set_initial_from_x0(x0)
+        for kk in range(3):
+            s.iterate(kk)
+        res.append((s.current(), s.scalars()))
+        if arena is not None:
+            inside = lambda t: any(sg[0] <= t.data_ptr() and t.data_ptr() + t.numel() * t.element_size() <= sg[0] + sg[2] for sg in ar.segments)
+            assert all(inside(t) for t in [s.ws] + s.xb + s.ub)
+            assert len(ar.handles) == (7 if chunk is None else -(-ar.segments[0][2] // chunk))
+        del s
+    (xa, ua), sa = res[0]
+    (xb, ub), sb = res[1]
+    assert np.array_equal(xa, xb) and np.array_equal(ua, ub)
+    for key in sa:
+        assert np.array_equal(sa[key], sb[key]), key
+    torch.cuda.synchronize()
+    ar.close()
