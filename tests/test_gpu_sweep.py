@@ -95,7 +95,7 @@ def test_parity_sweep(dist, prob, B, n_it):
     check_sweep(out, B, n_it)
 
 
-@pytest.mark.parametrize("dist,prob,B,n_it", [("random", "step", 4096, 20), ("perturbed", "step", 4096, 12)])
+@pytest.mark.parametrize("dist,prob,B,n_it", [("random", "step", 4096, 20), ("perturbed", "step", 4096, 12), ("perturbed", "acro", 2048, 12)])
 def test_parity_sweep_large_batch_kernels(tuned, dist, prob, B, n_it):
     """The same sweep, same gates, through the kernels the headline of bench.py times: one wavefront per tile in every
     pass, the states re-computed in the forward pass, two candidates riding along, the work-list line search —
@@ -105,7 +105,7 @@ def test_parity_sweep_large_batch_kernels(tuned, dist, prob, B, n_it):
     tuned(**LARGE_BATCH_KERNELS)
     out = parity_sweep.sweep(aoc, problems, B, n_it, dist, prob)
     out["tuning"] = LARGE_BATCH_KERNELS
-    _dump(out, "parity_sweep_large_kernels_%s_%s.json" % (dist, prob))
+    _dump(out, "parity_sweep_large_kernels_%s_%s.json" % (dist, prob))   # (the acrobatic case: T = 1000, the kernels configs[2]'s fp64 path runs at 65 536)
     check_sweep(out, B, n_it)
 
 
