@@ -188,16 +188,24 @@ __device__ __forceinline__ void pin_trig(TrigK<double>& K) {
     vpin(K.c5); vpin(K.c4); vpin(K.c3); vpin(K.c2); vpin(K.c1); vpin(K.c0);
 }
 __device__ __forceinline__ void pin_trig(TrigK<float>&) {}
-template <bool DIAG>
-__device__ __forceinline__ void pin_consts(KConst& k) {
+// the two halves of pin_consts, for kernels whose wavefronts play different roles (k_forward_duo): a role pins what IT uses
+__device__ __forceinline__ void pin_model(KConst& k) {
     vpin(k.cd0); vpin(k.cda); vpin(k.cla); vpin(k.m); vpin(k.g); vpin(k.S); vpin(k.rho); vpin(k.J); vpin(k.dt);
     vpin(k.dtm); vpin(k.mg); vpin(k.hrho); vpin(k.krs); vpin(k.b41); vpin(k.rJ);
+}
+template <bool DIAG>
+__device__ __forceinline__ void pin_weights(KConst& k) {
 #pragma unroll
     for (int i = 0; i < 36; i++)
         if (!DIAG || i % 7 == 0) { vpin(k.Q[i]); vpin(k.QT[i]); }
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (!DIAG || i % 3 == 0) vpin(k.R[i]);
+}
+template <bool DIAG>
+__device__ __forceinline__ void pin_consts(KConst& k) {
+    pin_model(k);
+    pin_weights<DIAG>(k);
 }
 
 // one fused multiply-add in the arithmetic type (a bare __builtin_fma on floats is a DOUBLE fma between two conversions)

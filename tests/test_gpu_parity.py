@@ -777,7 +777,7 @@ def test_forward_pass_with_a_linearisation_wavefront_changes_nothing(aoc, tuned)
         for ns in (2, 3, 7, 10):
             res = []
             for lin in (0, 1):
-                tuned(nspec=ns, fw_lin=lin)
+                tuned(nspec=ns, fw_lin=lin, fw_duo=0)
                 s = aoc.NewtonBatchSolver(bp, B, prm)
                 s.set_initial_from_x0(x0)
                 res.append((s.run_fixed(11 if ns == 10 else 4), s.current(), s.direction()))
@@ -793,7 +793,7 @@ def test_forward_pass_with_a_linearisation_wavefront_changes_nothing(aoc, tuned)
     bp = aoc.BatchProblem(pg["QQt"], pg["RRt"], pg["QQT"], pg["xx_ref"], pg["uu_ref"], float(pg["dt"]))
     out = []
     for lin in (0, 1):
-        tuned(fw_lin=lin)
+        tuned(fw_lin=lin, fw_duo=0)
         s = aoc.NewtonBatchSolver(bp, 3, aoc.make_params(stepsize_0=1.0, armijo_maxiters=10))
         xi = np.repeat(g["xx_init"][None], 3, 0) * (1 + 1e-13 * np.arange(3)[:, None, None])
         s.set_initial(xi, np.repeat(g["uu_init"][None], 3, 0))
@@ -802,6 +802,65 @@ def test_forward_pass_with_a_linearisation_wavefront_changes_nothing(aoc, tuned)
     for key in out[0][0]:
         assert np.array_equal(out[0][0][key], out[1][0][key], equal_nan=True), key
     assert np.array_equal(out[0][1][0], out[1][1][0]) and np.array_equal(out[0][1][1], out[1][1][1])
+
+
+def test_forward_pass_on_seven_roles_changes_nothing(aoc, tuned):
+    """k_forward_duo (aoc_tuning.fw_duo; round 5): the forward pass of tiny batches with the stage cut into seven roles
+    (two nominal-point producers, the LQR recursion, two candidates as state chain | cost).  Same operations on the same
+    values as k_forward_split: iterates, directions, steps, trial counts, costs, descents and status flags bit-identical —
+    with 4, 7, 10 and 11 candidates riding along (spare candidate of the last group, candidate stores with and without a
+    hint, the step of an exhausted search as candidate 10), on a ragged batch, across the Hessian switch, for even and odd
+    numbers of stages down to T = 3, with per-trajectory reference curves, with dense weights and for a caller-supplied
+    fp64 initial iterate."""
+    from aircraftoptimalcontrol_amd import problems
+    prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
+
+    def both(bp, B, x0, n_it, ns, init=None):
+        res = []
+        for duo in (0, 1):
+            tuned(nspec=ns, fw_duo=duo)
+            s = aoc.NewtonBatchSolver(bp, B, prm)
+            if init is None:
+                s.set_initial_from_x0(x0)
+            else:
+                s.set_initial(*init)
+            res.append((s.run_fixed(n_it), s.current(), s.direction()))
+        (ha, (xa, ua), da), (hb, (xb, ub), db) = res
+        assert np.array_equal(xa, xb, equal_nan=True) and np.array_equal(ua, ub, equal_nan=True), (B, ns)
+        assert np.array_equal(da, db, equal_nan=True), (B, ns)
+        for a, b in zip(ha, hb):
+            for key in a:
+                assert np.array_equal(a[key], b[key], equal_nan=True), (B, ns, key)
+
+    for T, B in ((500, 200), (333, 70)):
+        pr = problems.step_maneuver(1.0, 1.0 / T)
+        bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+        x0 = problems.random_x0(B, seed=23)
+        for ns in (4, 7, 10, 11):
+            both(bp, B, x0, 11 if ns >= 10 else 4, ns)
+    # horizons shorter than the load rings and the hand-off blocks
+    pr = problems.step_maneuver(1.0, 2e-3)
+    for T in (3, 4, 5, 6, 9):
+        bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref[:, :T], pr.uu_ref[:, :T], pr.dt)
+        both(bp, 70, problems.perturbed_x0(pr, 70, seed=T), 3, 11)
+    # one reference curve per trajectory; dense weights
+    B = 130
+    XR, UR = np.repeat(pr.xx_ref[None], B, 0), np.repeat(pr.uu_ref[None], B, 0)
+    XR[B // 2:, 1] *= 0.9
+    both(aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, XR, UR, pr.dt), B, problems.perturbed_x0(pr, B, seed=4), 4, 11)
+    rng = np.random.default_rng(0)
+    Q, QT, R = pr.QQt.copy(), pr.QQT.copy(), pr.RRt.copy()
+    for M, sc in ((Q, 1e-3), (QT, 1e-2)):
+        A = rng.normal(size=(6, 6)) * sc
+        M += A @ A.T
+    R += np.array([[0.0, 2e-7], [2e-7, 0.0]])
+    both(aoc.BatchProblem(Q, R, QT, pr.xx_ref, pr.uu_ref, pr.dt), 70, problems.perturbed_x0(pr, 70, seed=5), 4, 11)
+    # a caller-supplied iterate with arbitrary fp64 samples is read as fp64 by the first iteration
+    g = load_golden("g6_chain_step_T500")
+    pg = load_golden("problem_step_T500")
+    bpg = aoc.BatchProblem(pg["QQt"], pg["RRt"], pg["QQT"], pg["xx_ref"], pg["uu_ref"], float(pg["dt"]))
+    xi = np.repeat(g["xx_init"][None], 3, 0) * (1 + 1e-13 * np.arange(3)[:, None, None])
+    both(bpg, 3, None, 2, 11, init=(xi, np.repeat(g["uu_init"][None], 3, 0)))
 
 
 def test_forward_state_recomputation_does_not_change_results(aoc, tuned):
