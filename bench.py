@@ -109,6 +109,8 @@ def kernel_names(ntiles, full):
     chain = "k_hcut_chain6<true>" if t.hcut_chain6 else "k_track_hcut_chain<true>"
     ngroups = -(-nspec // 3)
     wpe = 1 if (t.fw_wpe1 and ntiles * ngroups <= 256) else 2
+    duo_max = 256 if t.fw_duo == 1 else t.fw_duo
+    duo = duo_max > 0 and nspec > 3 and ntiles * ((nspec + 1) // 2) <= duo_max
     return {
         "backward": ("phase: " + ("k_bw_hcut_lam<true, false, float> (costate maps), " if full else "") +
                      "k_bw_hcut<true, false, float, false%s> (segment maps), %s, k_bw_hcut<true, false, float, true%s> (gains)%s: the horizon in %d segments"
@@ -119,7 +121,8 @@ def kernel_names(ntiles, full):
                     if (not full and ntiles <= min(t.bw4_tiles, t.split_bw_tiles)) else
                     ("k_backward2<%s, float>" if ntiles <= t.split_bw_tiles else "k_backward<%s, float>") % fl,
         # <diagonal, shared reference, 2 speculated trials, states re-computed (the iterates of the run are rollouts), float32 states>
-        "forward": ("k_forward_lin<true, false, float, %d>" % wpe if lin else "k_forward_split<true, false, float, %d>" % wpe) if small else
+        "forward": ("k_forward_duo<true, false, float>" if duo else "k_forward_lin<true, false, float, %d>" % wpe if lin
+                    else "k_forward_split<true, false, float, %d>" % wpe) if small else
                    "k_forward<true, false, 2, %s, float>" % ("true" if t.fw_recompute else "false"),
         "linesearch_update": "k_ls_final_split<true, false, float>" if small else "k_ls_final<true, false, float>",
         "linesearch_search": ("phase: k_ls_init_wl, k_ls_plan_wl, k_ls_trial_wl<true, false, %d, pinned|plain> x2, k_ls_replan" % max(t.ls_cpl, 1)) if wl
