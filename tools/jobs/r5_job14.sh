@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/r5j14
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for tag in base single pf2 pf6; do
+for tag in base b3; do
   L=aircraftoptimalcontrol_amd/lib/variants/libaoc_$tag.so; D=1
   [ $tag = base ] && L=aircraftoptimalcontrol_amd/lib/libaoc_hip.so
   [ $tag = split ] && L=aircraftoptimalcontrol_amd/lib/libaoc_hip.so && D=0
