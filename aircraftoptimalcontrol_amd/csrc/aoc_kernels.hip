@@ -447,7 +447,11 @@ int aoc_streams_concurrent(void* stream_a, void* stream_b) {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     auto destroy = [&] { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); };
     for (int i = 0; i < 3; i++)
-        if (hipEventCreate(&ev[i]) != hipSuccess) { destroy(); return check_launch("aoc_streams_concurrent") ? AOC_ELAUNCH : AOC_ELAUNCH; }
+        if (hipEventCreate(&ev[i]) != hipSuccess) {
+            destroy();
+            (void)check_launch("aoc_streams_concurrent");   // leaves the reason in aoc_last_hip_error()
+            return AOC_ELAUNCH;
+        }
     hipEvent_t e0 = ev[0], e1 = ev[1], e2 = ev[2];
     int verdict = AOC_ELAUNCH;     // until a repetition has run to its end
     const long long ticks = 20000;   // 100 MHz constant clock: ~0.2 ms per kernel (the verdict is relative to ONE kernel's time)
