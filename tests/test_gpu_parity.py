@@ -380,8 +380,10 @@ def test_shard_invariance_and_large_batch(aoc, tuned, horizon_cut):
     for bit; x0 is keyed by the global trajectory index.
     horizon_cut (the default for batches of at most 64 tiles, aoc_tuning.bw_hcut): the Gauss-Newton backward pass of
     the small launch evaluates the Riccati recursion in horizon segments — another order of the same arithmetic — so
-    there the comparison is: Armijo steps, trial counts and float32 states identical, costs and inputs equal to 1e-12
-    (measured 1e-14); with the cut switched off everything is bit for bit again."""
+    there the comparison is: costs and inputs equal to 1e-12 (measured 4e-14), float32 states identical except where an
+    input that moved in its 14th digit tips a rounding to float32 (measured: 0 or 1 state of 1.9 million, one float32
+    ulp, depending on where the cuts fall — tools/probes/cut_state_flips.py); with the cut switched off everything is
+    bit for bit again."""
     from aircraftoptimalcontrol_amd import problems
     if not horizon_cut:
         tuned(bw_hcut=0, track_hcut=0)
@@ -396,12 +398,17 @@ def test_shard_invariance_and_large_batch(aoc, tuned, horizon_cut):
         out.append((h, s.current()))
     (hb, (xb, ub)), (hs, (xs, us)), (ht, (xt, ut)) = out
     for (h2, x2, u2, lo) in ((hs, xs, us, 0), (ht, xt, ut, 65000)):
-        assert np.array_equal(xb[lo:lo + 640], x2)
         if horizon_cut:
+            a, b = xb[lo:lo + 640], x2
+            assert np.array_equal(a[:, :, 0], b[:, :, 0])                              # x0 itself (fp64)
+            a, b = a[:, :, 1:].astype(np.float32), b[:, :, 1:].astype(np.float32)      # the stored states are float32 values
+            ulps = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+            assert ulps.max() <= 1 and np.count_nonzero(ulps) <= 1e-5 * ulps.size, (ulps.max(), np.count_nonzero(ulps))
             ref = ub[lo:lo + 640]
             assert (np.abs(ref - u2).max(2) / np.maximum(np.abs(ref).max(2), 1e-3)).max() < 1e-12
             assert not np.array_equal(ref, u2), "the small launch is expected to take the horizon cut"
         else:
+            assert np.array_equal(xb[lo:lo + 640], x2)
             assert np.array_equal(ub[lo:lo + 640], u2)
         for a, b in zip(hb, h2):
             for key in ("stepsize", "ntrials", "cost", "cost_new", "descent"):
