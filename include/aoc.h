@@ -57,7 +57,7 @@ extern "C" {
  *      search (armijo_maxiters + 1 where every candidate rides along)
  *   5: aoc_mpc_step takes aoc_mpc_noise (the disturbance drawn on the device) and disturbance_out; the horizon cut is
  *      decided once per aoc_newton_solve from the caller's batch (a trajectory's bits no longer depend on the generation or
- *      half it is solved in); aoc_tuning.fw_wpe1, hcut_chain6, bw_hcut_full, fw_duo */
+ *      half it is solved in); aoc_tuning.fw_wpe1, hcut_chain6, bw_hcut_full, fw_duo, hcut_waves */
 #define AOC_ABI_VERSION 5
 
 #define AOC_TILE 64
@@ -173,6 +173,10 @@ typedef struct aoc_tuning {
     int32_t fw_duo;            /* AOC_FW_DUO            forward pass of tiny batches (every candidate rides along, tiles x ceil(candidates / 2) <= 256)
                                   with the stage on seven roles, two candidates per workgroup (k_forward_duo); 0 = never, 1 = up to 256 workgroups,
                                   n > 1 = up to n workgroups (1) */
+    int32_t hcut_waves;        /* AOC_HCUT_WAVES        segment kernels of the horizon cut on three / two wavefronts per (tile, segment) (linearisation |
+                                  H half | Phi half of a map stage; linearisation | recursion and gains: k_*_hcut_map3, k_*_hcut_gains2), bit-identical
+                                  to the one-wavefront kernels; 0 = never, 1 = where every workgroup gets a CU of its own (tiles x segments <= 256),
+                                  2 = always (1) */
 } aoc_tuning;
 void aoc_get_tuning(aoc_tuning *out);
 void aoc_set_tuning(const aoc_tuning *t);

@@ -134,6 +134,50 @@ def test_six_wavefront_chain_equals_the_one_wavefront_chain(tuned, B):
                 assert np.array_equal(a[key], b[key]), key
 
 
+@pytest.mark.parametrize("B", [70, 1024, 4096])
+def test_segment_kernels_on_several_wavefronts_change_nothing(tuned, B):
+    """aoc_tuning.hcut_waves (round 5): the segment kernels of the horizon cut with a map stage on three wavefronts
+    (linearisation | H half | Phi half: k_track_hcut_map3, k_bw_hcut_map3) and the recursions on two (k_*_hcut_gains2),
+    against the one-wavefront kernels: same expressions, the values that cross between wavefronts are opaque to the
+    compiler in the one-wavefront kernels, so gains, iterates and every scalar are bit-identical — Gauss-Newton and
+    full-Hessian backward passes of the Newton iteration, and the tracking gains of aoc_mpc_step.  (4096 trajectories:
+    64 tiles, more wavefronts than SIMDs, forced with hcut_waves = 2.)"""
+    from aircraftoptimalcontrol_amd import batch as aoc, mpc, problems
+    pr = problems.step_maneuver(1.0, 2e-3)
+    bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
+    x0 = problems.perturbed_x0(pr, B, seed=5)
+    s = aoc.NewtonBatchSolver(bp, B, aoc.make_params(stepsize_0=1.0, armijo_maxiters=10))
+    res = []
+    for w in (0, 2):
+        tuned(hcut_waves=w)
+        s.set_initial_from_x0(x0)
+        out = []
+        for kk in (0, 1, 9, 10):      # two Gauss-Newton iterations, two with the full Hessian
+            s.iterate(kk)
+            out.append((_gains(s), s.current(), s.scalars()))
+        res.append(out)
+    for a, b in zip(*res):
+        assert np.array_equal(a[0], b[0], equal_nan=True)
+        assert np.array_equal(a[1][0], b[1][0], equal_nan=True) and np.array_equal(a[1][1], b[1][1], equal_nan=True)
+        for key in a[2]:
+            assert np.array_equal(a[2][key], b[2][key], equal_nan=True), key
+    if B <= 1024:
+        T, L = 200, 240
+        full = problems.step_maneuver(tf=1.0, dt=1.0 / L)
+        prm_ = problems.ProblemData("mpc", full.QQt, full.RRt, full.QQT, full.xx_ref, full.uu_ref, full.tt, full.tf, full.dt)
+        outs = []
+        for w in (0, 2):
+            tuned(hcut_waves=w)
+            rh = mpc.RecedingHorizon(prm_, problems.tracking_weights(), B, T, n_newton=2, sigma=np.array([0.02, 0.02, 0.02, 0.002, 0.004, 0.002]))
+            rh.start(problems.perturbed_x0(prm_, B, seed=1), cold_iters=4)
+            o = [rh.step() for _ in range(3)]
+            outs.append((rh.Kg.cpu().numpy().copy(), o))
+        assert np.array_equal(outs[0][0], outs[1][0])
+        for a, b in zip(outs[0][1], outs[1][1]):
+            for key in a:
+                assert np.array_equal(a[key], b[key]), key
+
+
 @pytest.mark.parametrize("level", [1, 2])
 def test_full_hessian_cut_against_the_sequential_kernels(tuned, level):
     """The horizon cut of FULL-HESSIAN backward passes (round 5: costate maps, value-function maps with the Hessian terms,
