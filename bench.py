@@ -113,9 +113,13 @@ def kernel_names(ntiles, full):
     duo = duo_max > 0 and nspec > 3 and ntiles * ((nspec + 1) // 2) <= duo_max
     return {
         "backward": ("phase: " + ("k_bw_hcut_lam<true, false, float> (costate maps), " if full else "") +
-                     "k_bw_hcut<true, false, float, false%s> (segment maps), %s, k_bw_hcut<true, false, float, true%s> (gains)%s: the horizon in %d segments"
-                     % (", true" if full else "", chain, ", true" if full else "",
-                        ", k_backward2<true, false, true, true, float> (lanes with an indefinite M)" if full else "", hcut))
+                     ("k_bw_hcut_map3<true, false, float, %s> (segment maps, a stage on three wavefronts), %s, k_bw_hcut_gains2<true, false, float, %s> (gains)%s: the horizon in %d segments"
+                      % ("true" if full else "false", chain, "true" if full else "false",
+                         ", k_backward2<true, false, true, true, float> (lanes with an indefinite M)" if full else "", hcut)
+                      if (t.hcut_waves >= 2 or (t.hcut_waves == 1 and ntiles * hcut <= 256)) else
+                      "k_bw_hcut<true, false, float, false%s> (segment maps), %s, k_bw_hcut<true, false, float, true%s> (gains)%s: the horizon in %d segments"
+                      % (", true" if full else "", chain, ", true" if full else "",
+                         ", k_backward2<true, false, true, true, float> (lanes with an indefinite M)" if full else "", hcut)))
                     if hcut >= 2 and ntiles * hcut <= 1024 else
                     ("k_backward5<true, false, float>" if t.bw5 else "k_backward4<true, false, false, false, float>")
                     if (not full and ntiles <= min(t.bw4_tiles, t.split_bw_tiles)) else
