@@ -105,7 +105,7 @@ def kernel_names(ntiles, full):
     small = ntiles <= t.split_tiles
     nspec = _lib.lib().aoc_default_nspec(ntiles * 64, 10)
     lin = t.fw_lin > 0 or (t.fw_lin < 0 and nspec <= 2)
-    hcut = (t.bw_hcut if t.bw_hcut >= 0 else (16 if ntiles <= 64 else 0)) if (not full or t.bw_hcut_full) else 0
+    hcut = (t.bw_hcut if t.bw_hcut >= 0 else (16 if ntiles <= 64 else 8 if (ntiles <= 128 and not full) else 0)) if (not full or t.bw_hcut_full) else 0
     chain = "k_hcut_chain6<true>" if t.hcut_chain6 else "k_track_hcut_chain<true>"
     ngroups = -(-nspec // 3)
     wpe = 1 if (t.fw_wpe1 and ntiles * ngroups <= 256) else 2

@@ -159,9 +159,10 @@ typedef struct aoc_tuning {
     int32_t solve_sync_fast;   /* AOC_SOLVE_SYNC_FAST   ... and reads the count every this many iterations once trajectories have begun to stop (2) */
     int32_t solve_split_tiles; /* AOC_SOLVE_SPLIT_TILES aoc_newton_solve2 cuts batches of at least this many tiles in two halves on its two streams (2048) */
     int32_t track_hcut;        /* AOC_TRACK_HCUT        aoc_mpc_step: tracking gains with the HORIZON cut in this many segments that run in parallel
-                                  (k_track_hcut_*; 0 = never, -1 = 16 for batches of at most 64 tiles (-1)).  Unlike every other knob this one
+                                  (k_track_hcut_*; 0 = never, -1 = 16 for batches of at most 64 tiles, 8 up to 128 tiles (-1)).  Unlike every other knob this one
                                   changes the order of the arithmetic: gains agree with the sequential kernels to ~1e-14 of their scale */
-    int32_t bw_hcut;           /* AOC_BW_HCUT           the same for the Gauss-Newton backward pass of aoc_newton_iterate (k_bw_hcut) (-1) */
+    int32_t bw_hcut;           /* AOC_BW_HCUT           the same for the Gauss-Newton backward pass of aoc_newton_iterate (k_bw_hcut; full-Hessian passes, see bw_hcut_full: at most
+                                  64 tiles) (-1) */
     int32_t fw_wpe1;           /* AOC_FW_WPE1           small-batch forward pass: launches of at most one workgroup per CU run the build
                                   compiled for one wavefront per SIMD (512 registers, nothing spilt) (1) */
     int32_t hcut_chain6;       /* AOC_HCUT_CHAIN6       horizon cut: the serial chain of boundary hops on four wavefronts per tile (three take two
@@ -242,7 +243,7 @@ int aoc_rollout_cost(const aoc_problem *prob, const double *x0, const double *u,
  * Kt: [ntiles][T][7][64][2] doubles, elem(b,t,p,row) at ((((b/64)*T + t)*7 + p)*64 + b%64)*2 + row — the size of a
  * tiled C=14 array, aoc_tiled_elems(B,T,14); sample T-1 unused.
  * lmbd0 (optional, [ntiles][6][64]) receives lambda_0 (forces the costate sweep).
- * scratch (may be NULL): device memory of scratch_bytes bytes that lets a Gauss-Newton pass of a batch of at most 64 tiles
+ * scratch (may be NULL): device memory of scratch_bytes bytes that lets a Gauss-Newton pass of a batch of at most 128 tiles
  * run with the horizon cut in parallel segments (aoc_tuning.bw_hcut; aoc_backward_scratch_bytes(B, T) says how much it
  * takes; aoc_newton_iterate lends the part of its workspace behind K~).  Without it the sequential kernels run. */
 size_t aoc_backward_scratch_bytes(int32_t B, int32_t T);

@@ -20,7 +20,7 @@ def _gains(s):
     return aoc.unpack_gains(Kt.view(s.nt, s.T, 14, 64), s.B).cpu().numpy()[..., :-1]
 
 
-@pytest.mark.parametrize("B", [1, 70, 1000, 4096])
+@pytest.mark.parametrize("B", [1, 70, 1000, 4096, 8000])
 def test_cut_backward_pass_equals_the_sequential_one(tuned, B):
     """One Gauss-Newton iteration with the backward pass cut in 4, 8, 16 segments (and whatever the default picks)
     against the sequential multi-wavefront kernels: every gain within 1e-12 of the largest gain of its column (measured
@@ -66,8 +66,8 @@ def test_cut_backward_pass_equals_the_sequential_one(tuned, B):
         # nine iterations free-running: 1e-14 grows along the ill-conditioned trajectories of the random starts (measured
         # 1.8e-8 on one of 4096; 2e-14 from perturbed starts)
         assert chan.max() < 1e-6 and np.median(chan) < 1e-11, (S, chan.max(), np.median(chan))
-    if B <= 4096:   # the default cuts batches of at most 64 tiles: not the sequential result bit for bit
-        assert not np.array_equal(out[-1][0], K0) and np.array_equal(out[-1][0], out[16][0])
+    # the default cuts batches of at most 64 tiles in 16 segments, up to 128 tiles in 8: not the sequential result bit for bit
+    assert not np.array_equal(out[-1][0], K0) and np.array_equal(out[-1][0], out[16 if B <= 4096 else 8][0])
 
 
 def test_cut_tracking_gains_equal_the_sequential_ones(tuned):
@@ -304,18 +304,19 @@ def test_full_hessian_cut_against_the_sequential_kernels(tuned, level):
 
 
 def test_large_batches_are_not_cut(tuned):
-    """Batches above 64 tiles keep the sequential kernels whatever the knob says, and with bw_hcut_full = 0 so do the
-    full-Hessian iterations (kk > 8) of small ones: bit-identical results with the cut forced on and off."""
+    """Batches above 128 tiles keep the sequential kernels by default (above 64 tiles for the full-Hessian iterations), and
+    with bw_hcut_full = 0 so do the full-Hessian iterations (kk > 8) of small ones: bit-identical results with the cut
+    switched off (bw_hcut = 0) and left to the default (-1)."""
     from aircraftoptimalcontrol_amd import batch as aoc, problems
     pr = problems.step_maneuver(1.0, 2e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
-    for B, kks in ((300, (9, 10)), (65 * 64 + 1, (0, 1))):
+    for B, kks, full in ((300, (9, 10), 0), (128 * 64 + 1, (0, 1), 2), (64 * 64 + 1, (9, 10), 2)):
         x0 = problems.perturbed_x0(pr, B, seed=3)
         s = aoc.NewtonBatchSolver(bp, B, prm)
         res = []
         for S in (0, -1):
-            tuned(bw_hcut=S, bw_hcut_full=0)
+            tuned(bw_hcut=S, bw_hcut_full=full)
             s.set_initial_from_x0(x0)
             for kk in kks:
                 s.iterate(kk)

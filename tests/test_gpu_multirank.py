@@ -35,7 +35,7 @@ def _bench(tmp, gpus, per_gpu, steps=3, extra=("--cpu-budget-s", "1.5"), light=F
 
 
 def test_two_ranks_through_the_real_solver_equal_one_process(tmp_path):
-    per = 4160                                  # 65 tiles per rank; the single process solves all 8320 at once
+    per = 8256                                  # 129 tiles per rank (above the horizon cut of small batches); the single process solves all 16 512 at once
     two, parts = _bench(tmp_path, 2, per)
     one, (whole,) = _bench(tmp_path, 1, 2 * per)
     assert two["n_gpus"] == 2 and one["n_gpus"] == 1
@@ -82,7 +82,7 @@ def test_two_ranks_through_the_real_solver_equal_one_process(tmp_path):
 def test_strong_scaling_option_splits_a_global_batch(tmp_path):
     """--global-batch G: the same total work over N ranks ("scaling": "strong"); each rank owns G / N contiguous global
     indices, so the shards of a 2-rank run are the halves of the 1-rank run."""
-    G = 2 * 4160
+    G = 2 * 8256
     two, parts = _bench(tmp_path, 2, 0, steps=2, extra=("--global-batch", str(G), "--no-cpu-baseline"))
     assert two["scaling"] == "strong" and two["config"]["global_batch"] == G and two["config"]["batch_per_gpu"] == G // 2
     assert [int(p["first"]) for p in parts] == [0, G // 2] and parts[0]["xx"].shape[0] == G // 2
