@@ -9,7 +9,8 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("AOC_LIB") or os.path.join(_PKG, "lib", "libaoc_hip.so")  # AOC_LIB: experiment builds
-_SRC = [os.path.join(_PKG, "csrc", f) for f in ("aoc_kernels.hip", "aoc_device.h", "aoc_passes.inc")]
+_SRC = [os.path.join(_PKG, "csrc", f) for f in ("aoc_kernels.hip", "aoc_device.h", "aoc_passes.inc")]   # [0]: the translation unit
+_SRC += sorted(os.path.join(_PKG, "csrc", "passes", f) for f in os.listdir(os.path.join(_PKG, "csrc", "passes")) if f.endswith(".inc"))
 _HDR = os.path.join(os.path.dirname(_PKG), "include", "aoc.h")
 
 AOC_TILE = 64

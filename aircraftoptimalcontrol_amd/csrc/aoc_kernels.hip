@@ -5,8 +5,10 @@
 // batch axis is the lane axis, so each (t, component) access of a wavefront is one coalesced 512-B
 // segment and a wavefront streams through its own contiguous slab of every array.
 // No MFMA (the blocks are 6x6/6x2); the per-lane state (P: 21, p: 6, lambda: 6 doubles, ...) lives in VGPRs.
-// The kernels themselves are in aoc_passes.inc (+ aoc_device.h), compiled twice: fp64 (aoc64, the
-// parity path) and float32 (aoc32, BASELINE config 3); this file holds what is common and the C-ABI.
+// The kernels themselves are in aoc_passes.inc (which includes passes/*.inc, one file per pass: layout, unit, cost_rollout,
+// backward, forward, tracking, hcut, ltv_lqr, linesearch, mpc; then the launch functions api.inc and the solve loop
+// solve.inc) + aoc_device.h, compiled twice: fp64 (aoc64, the parity path) and float32 (aoc32, BASELINE config 3); this file
+// holds what is common and the C-ABI.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>

@@ -1,7 +1,7 @@
 """Which lanes does the full-Hessian horizon cut hand to the sequential kernel, and why?  (diagnostic; needs a GPU)
     python tools/hcut_full_stats.py [B=4096] [dist=perturbed|random] [kk_max=14]
 Runs Newton iterations kk = 0..kk_max; before every full-Hessian iteration calls aoc_backward on the current iterate with a
-scratch region of its own and reads the cut's per-lane flag words back (csrc/aoc_passes.inc: HcutFull.lane_flags)."""
+scratch region of its own and reads the cut's per-lane flag words back (csrc/passes/hcut.inc: HcutFull.lane_flags)."""
 import ctypes as C
 import sys
 sys.path.insert(0, '.')
