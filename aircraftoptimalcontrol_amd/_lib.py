@@ -70,7 +70,7 @@ class Tuning(C.Structure):
                                          "trial_split", "solve_norepack", "ls_worklist", "ls_cpl", "ls_depth_min",
                                          "fw_recompute", "store_candidates", "bw4_tiles", "bw5", "solve_repack_pct",
                                          "solve_sync_fast", "solve_split_tiles", "track_hcut", "bw_hcut", "fw_wpe1",
-                                         "hcut_chain6", "bw_hcut_full", "fw_duo", "hcut_waves")]
+                                         "hcut_chain6", "bw_hcut_full", "fw_duo", "hcut_waves", "hcut_pairs")]
 
 
 # every symbol include/aoc.h declares: (name, restype, argtypes)

@@ -183,6 +183,7 @@ static void tuning_defaults(aoc_tuning* t) {
     t->bw_hcut_full = env("AOC_BW_HCUT_FULL", 2);
     t->fw_duo = env("AOC_FW_DUO", 1);
     t->hcut_waves = env("AOC_HCUT_WAVES", 1);
+    t->hcut_pairs = env("AOC_HCUT_PAIRS", 1);
 }
 
 static const aoc_tuning& tuning() {

@@ -107,6 +107,8 @@ def kernel_names(ntiles, full):
     lin = t.fw_lin > 0 or (t.fw_lin < 0 and nspec <= 2)
     hcut = (t.bw_hcut if t.bw_hcut >= 0 else (16 if ntiles <= 64 else 8 if (ntiles <= 128 and not full) else 0)) if (not full or t.bw_hcut_full) else 0
     chain = "k_hcut_chain6<true>" if t.hcut_chain6 else "k_track_hcut_chain<true>"
+    if not t.hcut_chain6 and hcut >= 4 and (t.hcut_pairs >= 2 or (t.hcut_pairs == 1 and hcut >= 12)):
+        chain = "k_hcut_pair<true> (maps composed pairwise), k_track_hcut_chain<true>, k_hcut_odd<true>"
     ngroups = -(-nspec // 3)
     wpe = 1 if (t.fw_wpe1 and ntiles * ngroups <= 256) else 2
     duo_max = 256 if t.fw_duo == 1 else t.fw_duo

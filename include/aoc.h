@@ -57,7 +57,7 @@ extern "C" {
  *      search (armijo_maxiters + 1 where every candidate rides along)
  *   5: aoc_mpc_step takes aoc_mpc_noise (the disturbance drawn on the device) and disturbance_out; the horizon cut is
  *      decided once per aoc_newton_solve from the caller's batch (a trajectory's bits no longer depend on the generation or
- *      half it is solved in); aoc_tuning.fw_wpe1, hcut_chain6, bw_hcut_full, fw_duo, hcut_waves */
+ *      half it is solved in); aoc_tuning.fw_wpe1, hcut_chain6, bw_hcut_full, fw_duo, hcut_waves, hcut_pairs */
 #define AOC_ABI_VERSION 5
 
 #define AOC_TILE 64
@@ -178,6 +178,11 @@ typedef struct aoc_tuning {
                                   H half | Phi half of a map stage; linearisation | recursion and gains: k_*_hcut_map3, k_*_hcut_gains2), bit-identical
                                   to the one-wavefront kernels; 0 = never, 1 = where every workgroup gets a CU of its own (tiles x segments <= 256),
                                   2 = always (1) */
+    int32_t hcut_pairs;        /* AOC_HCUT_PAIRS        the maps of neighbouring segments of the horizon cut composed pairwise before the chain of
+                                  boundary hops (k_hcut_pair, k_hcut_odd): about S/2 + 2 hop-times in series instead of S - 2.  Like the cut
+                                  itself another order of the same arithmetic (gains to 1e-14 of their scale); 0 = never, 1 = for cuts in
+                                  at least 12 segments (i.e. where the cut itself is decided: by the caller's tile count), 2 = whenever
+                                  there is a pair (1) */
 } aoc_tuning;
 void aoc_get_tuning(aoc_tuning *out);
 void aoc_set_tuning(const aoc_tuning *t);

@@ -54,7 +54,7 @@ def test_geometry_helpers_and_errors():
     assert C.sizeof(_lib.Model) == 72
     assert C.sizeof(_lib.Problem) == 72 + 76 * 8 + 32 + 16
     assert C.sizeof(_lib.Params) == 48
-    assert C.sizeof(_lib.Tuning) == 100   # 25 int32 (round 5: fw_wpe1, hcut_chain6, bw_hcut_full, fw_duo, hcut_waves)
+    assert C.sizeof(_lib.Tuning) == 104   # 26 int32 (round 5: fw_wpe1, hcut_chain6, bw_hcut_full, fw_duo, hcut_waves, hcut_pairs)
     assert C.sizeof(_lib.MpcNoise) == 64  # uint64 seed, two uint32, six doubles (ABI revision 5)
     assert lib.aoc_abi_version() == _lib.AOC_ABI_VERSION == 5
     # argument errors are reported before anything touches a device

@@ -13,6 +13,16 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
+def _same_float32_states(xa, xb, frac=1e-5):
+    """The cut moves inputs in their 14th digit; a float32 state stays what it was unless that tips a rounding (measured:
+    0 or 1 element of 1.9 million, one ulp — tools/probes/cut_state_flips.py).  Sample 0 is the caller's fp64 x0."""
+    if not np.array_equal(xa[:, :, 0], xb[:, :, 0]):
+        return False
+    a, b = xa[:, :, 1:].astype(np.float32), xb[:, :, 1:].astype(np.float32)
+    ulps = np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64))
+    return ulps.max() <= 1 and np.count_nonzero(ulps) <= max(1, frac * ulps.size)
+
+
 def _gains(s):
     from aircraftoptimalcontrol_amd import batch as aoc
     Kt = s._carve()[0]
@@ -25,7 +35,8 @@ def test_cut_backward_pass_equals_the_sequential_one(tuned, B):
     """One Gauss-Newton iteration with the backward pass cut in 4, 8, 16 segments (and whatever the default picks)
     against the sequential multi-wavefront kernels: every gain within 1e-12 of the largest gain of its column (measured
     1e-14), direction and descent within 1e-11, the same Armijo step and trial count for every trajectory, the same new
-    float32 states; then nine iterations free-running: identical step and trial histories."""
+    float32 states (but for a rounding tipped once in a million); then nine iterations free-running: identical step and
+    trial histories."""
     from aircraftoptimalcontrol_amd import batch as aoc, problems
     pr = problems.step_maneuver(1.0, 2e-3)
     bp = aoc.BatchProblem(pr.QQt, pr.RRt, pr.QQT, pr.xx_ref, pr.uu_ref, pr.dt)
@@ -33,10 +44,14 @@ def test_cut_backward_pass_equals_the_sequential_one(tuned, B):
     prm = aoc.make_params(stepsize_0=1.0, armijo_maxiters=10)
     s = aoc.NewtonBatchSolver(bp, B, prm)
     out = {}
-    for S in (0, 4, 8, 16, -1):
+    # (segments, maps of neighbouring segments composed pairwise before the chain: aoc_tuning.hcut_pairs); odd numbers of
+    # segments leave one plain hop behind the composed ones
+    for S in (0, 4, 8, 16, -1, (16, 0), (8, 2), (5, 2), (7, 2), (3, 2), (2, 2)):
+        S, pairs = S if isinstance(S, tuple) else (S, 1)
         if S > 0 and S * s.nt > 1024:
             continue
-        tuned(bw_hcut=S)
+        tuned(bw_hcut=S, hcut_pairs=pairs)
+        key = S if pairs == 1 else (S, pairs)
         s.set_initial_from_x0(x0)
         s.iterate(0)
         K = _gains(s)
@@ -46,7 +61,7 @@ def test_cut_backward_pass_equals_the_sequential_one(tuned, B):
             s.iterate(kk)
             sc2 = s.scalars()
             hist.append((sc2["stepsize"].copy(), sc2["ntrials"].copy()))
-        out[S] = (K, du, sc, xx, uu, hist, s.current())
+        out[key] = (K, du, sc, xx, uu, hist, s.current())
     K0, du0, sc0, xx0, uu0, hist0, (xf0, uf0) = out[0]
     kscale = np.abs(K0).max(axis=(0, 3), keepdims=True)
     for S, (K, du, sc, xx, uu, hist, (xf, uf)) in out.items():
@@ -57,7 +72,7 @@ def test_cut_backward_pass_equals_the_sequential_one(tuned, B):
         assert np.allclose(sc["descent"], sc0["descent"], rtol=1e-11, atol=0), S
         assert np.array_equal(sc["stepsize"], sc0["stepsize"]) and np.array_equal(sc["ntrials"], sc0["ntrials"]), S
         assert np.array_equal(sc["status"], sc0["status"]), S
-        assert np.array_equal(xx, xx0), S
+        assert _same_float32_states(xx, xx0), S
         for (a, b), (c, d) in zip(hist, hist0):
             assert np.array_equal(a, c) and np.array_equal(b, d), S
         same = sum(np.array_equal(xf[b], xf0[b]) for b in range(B))
@@ -68,11 +83,13 @@ def test_cut_backward_pass_equals_the_sequential_one(tuned, B):
         assert chan.max() < 1e-6 and np.median(chan) < 1e-11, (S, chan.max(), np.median(chan))
     # the default cuts batches of at most 64 tiles in 16 segments, up to 128 tiles in 8: not the sequential result bit for bit
     assert not np.array_equal(out[-1][0], K0) and np.array_equal(out[-1][0], out[16 if B <= 4096 else 8][0])
+    if (16, 0) in out:      # composing the maps is another order of the arithmetic again
+        assert not np.array_equal(out[(16, 0)][0], out[16][0])
 
 
 def test_cut_tracking_gains_equal_the_sequential_ones(tuned):
     """aoc_mpc_step's tracking gains (lqr_tracking.py:268-276) with the horizon cut against the sequential kernels: gains
-    within 1e-12 of their scale, the applied input within 1e-12, the plant state identical."""
+    within 1e-12 of their scale, the applied input within 1e-12, the plant state identical (or one float32 rounding apart)."""
     from aircraftoptimalcontrol_amd import mpc, problems
     T, steps, B = 500, 30, 200
     L = T + steps + 10
@@ -92,7 +109,7 @@ def test_cut_tracking_gains_equal_the_sequential_ones(tuned):
         assert (np.abs(K - K0) / scale).max() < 1e-12, S
         for a, b in zip(o, o0):
             assert np.abs(a["u_applied"] - b["u_applied"]).max() <= 1e-12 * np.abs(b["u_applied"]).max(), S
-            assert np.array_equal(a["x_true"], b["x_true"]), S
+            assert np.array_equal(a["x_true"], b["x_true"]) or np.abs(a["x_true"] - b["x_true"]).max() <= 2e-7 * np.abs(b["x_true"]).max(), S
             assert np.allclose(a["cost"], b["cost"], rtol=1e-12, atol=0), S
     assert np.array_equal(res[-1][0], res[16][0]) and not np.array_equal(res[16][0], K0)
 
@@ -109,7 +126,7 @@ def test_six_wavefront_chain_equals_the_one_wavefront_chain(tuned, B):
     s = aoc.NewtonBatchSolver(bp, B, aoc.make_params(stepsize_0=1.0, armijo_maxiters=10))
     res = []
     for c6 in (0, 1):
-        tuned(hcut_chain6=c6)
+        tuned(hcut_chain6=c6, hcut_pairs=0)
         s.set_initial_from_x0(x0)
         s.iterate(0)
         K = _gains(s)
@@ -125,7 +142,7 @@ def test_six_wavefront_chain_equals_the_one_wavefront_chain(tuned, B):
         prm_ = problems.ProblemData("mpc", full.QQt, full.RRt, full.QQT, full.xx_ref, full.uu_ref, full.tt, full.tf, full.dt)
         outs = []
         for c6 in (0, 1):
-            tuned(hcut_chain6=c6)
+            tuned(hcut_chain6=c6, hcut_pairs=0)
             rh = mpc.RecedingHorizon(prm_, problems.tracking_weights(), B, T, n_newton=2, sigma=np.array([0.02, 0.02, 0.02, 0.002, 0.004, 0.002]))
             rh.start(problems.perturbed_x0(prm_, B, seed=1), cold_iters=4)
             o = [rh.step() for _ in range(3)]
@@ -279,7 +296,7 @@ def test_full_hessian_cut_against_the_sequential_kernels(tuned, level):
         assert np.abs(du1[clean] - du0[clean]).max() <= 1e-9 * dscale
         assert np.allclose(sc1["descent"][clean], sc0["descent"][clean], rtol=1e-9, atol=0)
         assert np.array_equal(sc1["stepsize"][clean], sc0["stepsize"][clean]) and np.array_equal(sc1["ntrials"][clean], sc0["ntrials"][clean])
-        assert np.array_equal(it1[0][clean], it0[0][clean])
+        assert _same_float32_states(it1[0][clean], it0[0][clean])
         r = {"B": B, "lanes_regularised_or_singular": int(flagged.sum()), "gain_error_clean_lanes": float(kerr)}
         if flagged.any():
             fl = np.nonzero(flagged & okK)[0]
