@@ -258,7 +258,45 @@ def config1_full_solves():
     full_solve(acro_problem(), "g8_full_acro_T1000")
 
 
+def airfoil_vectors():
+    """the post-processing module animate.py (:6-140).  The outline of Airfoil(20, ...) (the thickness both
+    drivers use, main_newton_method.py:226, acrobatic_newton.py:242) and of a 12 % section, the outline at seeded random
+    poses through update_pose, and what animate(i) puts into its artists for a few frames of a seeded trajectory (the
+    artists are made here, as run_animation makes them, without rendering 1000 frames)."""
+    import matplotlib.pyplot as plt
+    import animate as ref_anim
+    rng = np.random.default_rng(20261005)
+    dt, TT = 0.05, 20
+    xs = np.stack([np.linspace(0, 16, TT), 3 * np.sin(np.linspace(0, 3, TT)), rng.uniform(9, 23, TT),
+                   rng.uniform(-3.2, 3.2, TT), rng.normal(0, 5, TT), rng.uniform(-1, 1, TT)])
+    xr = xs + rng.normal(0, 0.3, xs.shape)
+    af = ref_anim.Airfoil(20, xs, xr, dt=dt, xlim=[0, 17], ylim=[-5, 5])
+    outline20 = af.update_pose(0.0, 0.0, 0.0)            # T = identity
+    outline12 = ref_anim.Airfoil(12, xs, xr).update_pose(0.0, 0.0, 0.0)
+    n = 16
+    th, px, py = rng.uniform(-3.2, 3.2, n), rng.uniform(-2, 20, n), rng.uniform(-5, 5, n)
+    posed = np.stack([af.update_pose(th[i], px[i], py[i]) for i in range(n)])
+    fig, ax = plt.subplots()
+    af.line0, = ax.plot([], []); af.line1, = ax.plot([], []); af.point1, = ax.plot([], [])
+    af.time_template = 't = %.1f s'; af.time_text = ax.text(0, 0, '')
+    frames = np.array([0, 7, 19])
+    l0 = []; l1 = []
+    point_error = ""
+    for i in frames:
+        try:
+            af.animate(int(i))
+        except RuntimeError as e:        # Matplotlib >= 3.7 refuses the scalars animate.py:111 hands to point1.set_data:
+            point_error = str(e)         # the two outlines are set by then, the marker and the time label are not
+        l0.append(np.stack(af.line0.get_data())); l1.append(np.stack(af.line1.get_data()))
+    plt.close(fig)
+    save("g10_airfoil", xx_star=xs, xx_ref=xr, dt=np.float64(dt), outline20=outline20, outline12=outline12,
+         theta=th, x_loc=px, y_loc=py, posed=posed, frames=frames, line0=np.stack(l0), line1=np.stack(l1),
+         point_error=np.array(point_error))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "airfoil":     # only the fixture added in round 5
+        return airfoil_vectors()
     if len(sys.argv) > 1 and sys.argv[1] == "config1":   # only the fixtures added in round 2
         return config1_full_solves()
     rng = np.random.default_rng(20260331)
@@ -382,6 +420,7 @@ def main():
         XO[b], UO[b] = its[nit - 1]
         CO[b], DE[b], ST[b] = r["cost"], r["descent"], r["stepsize"]
     config1_full_solves()
+    airfoil_vectors()
     save("g9_minibatch_step_T500", x0=x0s, xx_init=XI, uu_init=UI, xx_out=XO.astype(np.float32),
          x0_out=XO[:, :, 0].copy(), uu_out=UO, cost=CO, descent=DE, stepsize=ST, n_iters=np.int64(nit))
 
