@@ -4,7 +4,7 @@ same problem, same solver settings, same artefacts (Data/xx_star*.npy, Data/uu_s
 float64 C-order), no cvxpy; Matplotlib only with --animate (the drivers' closing Airfoil(...).run_animation(...),
 main_newton_method.py:226-227, acrobatic_newton.py:242-243: Figures/AircraftBehavior_<step|acrobatic>.gif).
 
-    python examples/run_newton.py step      [--out Data] [--dt 1e-3] [--init fixture.npz] [--animate STRIDE]
+    python examples/run_newton.py step      [--out Data] [--dt 1e-3] [--init fixture.npz] [--animate STRIDE [--figures Figures]]
     python examples/run_newton.py acrobatic [--out Data]
 """
 import argparse
@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--init", default=None, help=".npz with xx_init (6,T), uu_init (2,T) instead of the P-controller guess")
     ap.add_argument("--animate", type=int, default=0, metavar="STRIDE",
                     help="write the drivers' GIF, every STRIDE-th frame (1 = all 1/dt frames as the reference does)")
+    ap.add_argument("--figures", default="Figures", help="directory of the GIF (the reference writes into Figures/)")
     a = ap.parse_args()
     pr = problems.step_maneuver(a.tf, a.dt) if a.problem == "step" else problems.acrobatic(a.tf, a.dt)
     dyn = Dynamics()
@@ -47,13 +48,14 @@ def main():
     np.save(os.path.join(a.out, "uu_star%s.npy" % suffix), uu_star)
     print("iterations: %d   cost: %.10g -> %.10g   saved to %s" % (NM.iters, NM.JJ[0], NM.JJ[-1], a.out))
     if a.animate > 0:
+        os.environ.setdefault("MPLBACKEND", "Agg")                   # headless driver: plt.show() returns at once
         from animate import Airfoil
         if a.problem == "step":                                      # main_newton_method.py:226-227
             craft, name = Airfoil(20, xx_star, pr.xx_ref, dt=a.dt, xlim=[0, 17], ylim=[-5, 5]), "step"
         else:                                                        # acrobatic_newton.py:139, :242-243
             xf, zf = 18, 2.71
             craft, name = Airfoil(20, xx_star, pr.xx_ref, dt=a.dt, xlim=[0, xf + 1], ylim=[-zf * 4, zf * 4]), "acrobatic"
-        print("animation:", craft.run_animation(name=name, stride=a.animate))
+        print("animation:", craft.run_animation(name=name, stride=a.animate, out_dir=a.figures))
 
 
 if __name__ == "__main__":

@@ -73,6 +73,18 @@ def test_run_newton_like_the_reference_scripts(tmp_path, problem, fixture, suffi
     assert np.abs(xs - f["xx_star"]).max() < 5e-3
 
 
+def test_run_newton_animates_like_the_drivers_closing_call(tmp_path):
+    """main_newton_method.py:226-227: Airfoil(20, xx_star, xx_ref, xlim=[0, 17], ylim=[-5, 5]).run_animation(name='step')
+    at the end of the driver; every 100th of the 1000 frames here."""
+    from PIL import Image
+    figs = tmp_path / "Figures"
+    out = _run("run_newton.py", "step", "--out", tmp_path, "--init", os.path.join(GOLDEN, "g8_full_step_T1000.npz"),
+               "--animate", 100, "--figures", figs)
+    assert "animation: %s" % (figs / "AircraftBehavior_step.gif") in out
+    with Image.open(figs / "AircraftBehavior_step.gif") as im:
+        assert im.n_frames == 10
+
+
 def test_run_lqr_tracking_on_the_references_optimum(tmp_path):
     """`python lqr_tracking.py` (lqr_tracking.py:321-342) on the reference's committed Data/xx_star.npy, uu_star.npy."""
     g = load_golden("g4_lqr_tracking")
