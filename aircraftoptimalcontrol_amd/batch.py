@@ -353,11 +353,11 @@ class NewtonBatchSolver:
             cbytes = 0
         return Kt, du, Jt, scratch, sbytes, nsp, cand, cbytes
 
-    def iterate_timed(self, kk=None):
-        """The launches of iterate(), issued pass by pass with HIP events recorded on the launch
-        stream between them: backward | forward | line-search rounds (aoc_linesearch_search) | final rollout
-        (aoc_linesearch_update = k_ls_final).  Returns the five events; read them after a synchronize with
-        ev[i].elapsed_time(ev[i+1]) [ms], i indexing PASSES."""
+    def iterate_passes(self, kk=None, between=None):
+        """The launches of iterate(), issued pass by pass through the four entry points aoc_newton_iterate is made of:
+        backward | forward | line-search rounds (aoc_linesearch_search) | final rollout (aoc_linesearch_update).
+        between(i), if given, is called on the host before pass i (i indexing PASSES) and once more, with i = 4, after
+        the last one — where a caller records events on the launch stream or makes it wait for another stream."""
         torch = _torch()
         if kk is None:
             kk = self.kk
@@ -367,27 +367,34 @@ class NewtonBatchSolver:
         c, n = self.cur, (self.cur + 1) % 3
         jc, jn = self.jcur, 1 - self.jcur
         Kt, du, Jt, scratch, sbytes, nsp, cand, cbytes = self._carve()
-        st = torch.cuda.current_stream(self.problem.device)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-        ev[0].record(st)
+        between = between or (lambda i: None)
+        between(0)
         # (what lies behind K~ in the workspace is free until the forward pass: scratch of the backward pass, as in aoc_newton_iterate)
         check(lib().aoc_backward(C.byref(p), int(kk > prm.hessian_switch), _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
                                  _ptr(Kt), None, _ptr(self.status), _ptr(du), (self.ws.numel() - Kt.numel()) * 8), "aoc_backward")
-        ev[1].record(st)
+        between(1)
         check(lib().aoc_forward(C.byref(p), C.byref(prm), nsp, _ptr(x), _ptr(self.ub[c]), _ptr(self.x0),
                                 _ptr(Kt), _ptr(du), _ptr(self.descent), _ptr(Jt), _ptr(self.status), _ptr(cand), cbytes,
                                 _ptr(self.ntrials)), "aoc_forward")
-        ev[2].record(st)
+        between(2)
         check(lib().aoc_linesearch_search(C.byref(p), C.byref(prm), nsp, _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
                                           _ptr(self.J[jc]), _ptr(self.descent), _ptr(Jt), _ptr(self.stepsize),
                                           _ptr(self.ntrials), _ptr(scratch), sbytes), "aoc_linesearch_search")
-        ev[3].record(st)
+        between(3)
         check(lib().aoc_linesearch_update(C.byref(p), C.byref(prm), _ptr(self.ub[c]), _ptr(self.x0), _ptr(du),
                                           _ptr(self.xb[n]), _ptr(self.ub[n]), _ptr(self.J[jn]), _ptr(self.stepsize),
                                           _ptr(self.ntrials), _ptr(self.status), _ptr(scratch), sbytes, nsp, _ptr(Jt),
                                           _ptr(cand), cbytes), "aoc_linesearch_update")
-        ev[4].record(st)
+        between(4)
         self.cur, self.jcur, self.kk, self.cur_is64, self.cur_rollout = n, jn, kk + 1, False, True
+
+    def iterate_timed(self, kk=None):
+        """iterate_passes() with HIP events recorded on the launch stream between the passes.  Returns the five events;
+        read them after a synchronize with ev[i].elapsed_time(ev[i+1]) [ms], i indexing PASSES."""
+        torch = _torch()
+        st = torch.cuda.current_stream(self.problem.device)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        self.iterate_passes(kk, lambda i: ev[i].record(st))
         return ev
 
     # -- results ---------------------------------------------------------------------------------
@@ -721,6 +728,8 @@ class TwoStreamNewtonSolver:
         # two streams on ONE hardware queue would take turns (concurrent_streams): checked once, here
         self.streams = list(streams) if streams is not None else concurrent_streams(problem.device, len(self.parts))
         self.kk = 0
+        self.phased = bool(int(os.environ.get("AOC_TWO_STREAM_PHASED", "0")))   # iterate_phased as the schedule of iterate()
+        self._search_done = [None, None]
 
     def _on(self, fn):
         torch = _torch()
@@ -742,16 +751,47 @@ class TwoStreamNewtonSolver:
         cut = (x0[:self.Ba], x0[self.Ba:])
         self._on(lambda i, sv: sv.set_initial_from_x0(cut[i], kp, kt))
         self.kk = 0
+        self._search_done = [None, None]
         self.join()
 
     def iterate(self, kk=None):
-        """One outer iteration of every trajectory: enqueued on the two streams, no join."""
+        """One outer iteration of every trajectory: enqueued on the two streams, no join (`phased`, off by default:
+        see iterate_phased)."""
         if kk is None:
             kk = self.kk
+        if self.phased:
+            return self.iterate_phased(kk)
         torch = _torch()
         for sv, st in zip(self.parts, self.streams):
             with torch.cuda.stream(st):
                 sv.iterate(kk)
+        self.kk = kk + 1
+
+    def iterate_phased(self, kk=None):
+        """iterate() with the two halves taking turns in their line-search rounds: a half's search waits
+        (hipStreamWaitEvent) for the end of the other half's previous search, so the order on the device is A0 B0 A1
+        B1 ... and every search runs beside the other half's update / backward / forward passes, never beside its
+        search (left to themselves only 40-60 % of a half's search time lies beside a streaming pass of the other one,
+        profiles/r05_head_overlap_two_streams.json).  Scheduling only: the same four entry points per half and iteration
+        as aoc_newton_iterate issues, results identical (tests/test_gpu_multirank.py).  MEASURED SLOWER and therefore
+        off (AOC_TWO_STREAM_PHASED=1 or .phased turns it on): 5.09 against 5.01 ms per iteration over kk 0..19, 4.73 / 4.58
+        over kk 0..9 (tools/phase_probe.py, one set of buffers) — the search is not idle time of the chip that a
+        schedule could fill: in the storm iterations its rollouts are ~1 ms of fp64 issue slots of the whole device per
+        iteration, and the streaming passes themselves keep the vector units busy for half of their duration
+        (EXPERIMENTS.md "Two streams, the search as a token")."""
+        if kk is None:
+            kk = self.kk
+        torch = _torch()
+        for i, (sv, st) in enumerate(zip(self.parts, self.streams)):
+            def between(j, i=i, st=st):
+                if j == 2 and self._search_done[1 - i] is not None:
+                    st.wait_event(self._search_done[1 - i])
+                elif j == 3:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    self._search_done[i] = ev
+            with torch.cuda.stream(st):
+                sv.iterate_passes(kk, between)
         self.kk = kk + 1
 
     def run_fixed(self, n_iters, kk0=None):

@@ -172,6 +172,16 @@ def test_two_stream_solver_equals_one_stream():
     ja, da, na = (t.cpu().numpy() for t in one.summary_tensors())
     jb, db, nb = (t.cpu().numpy() for t in two.summary_tensors())
     assert np.array_equal(ja, jb, equal_nan=True) and np.array_equal(da, db, equal_nan=True) and np.array_equal(na, nb)
+    # the same iterations issued pass by pass with the halves taking turns in their search rounds (iterate_phased:
+    # scheduling only — measured slower than free-running halves, off by default)
+    two.phased = True
+    two.set_initial_from_x0(x0)
+    two.run_fixed(11)
+    c = two.scalars()
+    for key in ("stepsize", "ntrials", "cost", "cost_new", "descent", "status"):
+        assert np.array_equal(a[key], c[key], equal_nan=True), key
+    xc, uc = two.current()
+    assert np.array_equal(xa, xc, equal_nan=True) and np.array_equal(ua, uc, equal_nan=True)
 
 
 def test_rccl_branch_on_one_gpu(tmp_path):
