@@ -479,6 +479,28 @@ def rel_err_vs_oracle(batch, bp, prm, pr, x0, sample, iters, K, cores):
     return out
 
 
+# SQ_INSTS_VALU per wavefront and stage of the large-batch kernels (profiles/r05_sq_counters.txt: rocprofv3 --pmc over the
+# one-stream run of this workload; round 3's record has the same counts) and the share of its cycles a wavefront of the
+# kernel spends issuing them, two such wavefronts per SIMD
+SQ_VALU_PER_WAVE_STAGE = {"k_forward<true, false, 2, true, float>": (624.2, 0.505),
+                          "k_backward<true, false, false, false, float>": (546.9, 0.336),
+                          "k_backward<true, false, true, true, float>": (593.4, 0.366),
+                          "k_ls_final<true, false, float>": (221.2, 0.276)}
+
+
+def vector_issue(dom, units):
+    """The dominant kernel against the fp64 issue roof: 1024 SIMDs, one vector instruction of a wavefront per 4 cycles,
+    2.4 GHz nominal (the clock held under this load is lower)."""
+    for name, (per_stage, issuing) in SQ_VALU_PER_WAVE_STAGE.items():
+        if dom["kernel"] == name:
+            insts = per_stage * units / 64.0
+            floor_ms = insts / (1024 * 2.4e9 / 4) * 1e3
+            return {"valu_insts_per_launch": insts, "issue_ms_at_2.4GHz": floor_ms, "frac": floor_ms / dom["avg_ms"],
+                    "wavefront_cycles_issuing_valu": issuing, "wavefronts_per_simd": 2,
+                    "source": "profiles/r05_sq_counters.txt (SQ counters of the one-stream run, per wavefront-stage)"}
+    return None
+
+
 def run(a):
     import torch
     import torch.distributed as dist
@@ -703,7 +725,10 @@ def run(a):
                      "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "stored_bytes_per_launch": dom["stored_bytes"],
                      "frac_stored": dom["frac_stored"], "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
                      "measured_in": ("one-stream repeat of the same %d iterations right after the timed region" % K)
-                     if overlap else "the timed region"},
+                     if overlap else "the timed region",
+                     # the same kernel against the other roof it touches: vector instructions per wavefront-stage from
+                     # the SQ counters of the committed one-stream run, priced at the nominal issue rate
+                     "vector_issue": vector_issue(dom, units)},
         "kernels": kernels,
         "attribution_ms_per_step": float(ms.sum(1).mean()),
         # whole iteration, per GPU: SURVEY 8d's 496 B per trajectory-stage over the wall time of a step
