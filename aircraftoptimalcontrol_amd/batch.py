@@ -776,8 +776,8 @@ class TwoStreamNewtonSolver:
         as aoc_newton_iterate issues, results identical (tests/test_gpu_multirank.py).  MEASURED SLOWER and therefore
         off (AOC_TWO_STREAM_PHASED=1 or .phased turns it on): 5.09 against 5.01 ms per iteration over kk 0..19, 4.73 / 4.58
         over kk 0..9 (tools/phase_probe.py, one set of buffers) — the search is not idle time of the chip that a
-        schedule could fill: beside the other half's streaming passes it takes 1.39 instead of 0.94 ms and stretches them
-        in turn (profiles/r05_head_overlap_two_streams.json, r05_sq_counters.txt)
+        schedule could fill: a half's search takes 0.86-1.26 ms per iteration beside the other half (the whole batch's on one
+        stream: 1.05 ms) and the passes beside it stretch (profiles/r05_head_overlap_two_streams.json, r05_sq_counters.txt)
         (EXPERIMENTS.md "Two streams, the search as a token")."""
         if kk is None:
             kk = self.kk
