@@ -488,12 +488,12 @@ SQ_VALU_PER_WAVE_STAGE = {"k_forward<true, false, 2, true, float>": (624.2, 0.50
                           "k_ls_final<true, false, float>": (221.2, 0.276)}
 
 
-def vector_issue(dom, units):
+def vector_issue(dom, units, T):
     """The dominant kernel against the fp64 issue roof: 1024 SIMDs, one vector instruction of a wavefront per 4 cycles,
     2.4 GHz nominal (the clock held under this load is lower)."""
     for name, (per_stage, issuing) in SQ_VALU_PER_WAVE_STAGE.items():
         if dom["kernel"] == name:
-            insts = per_stage * units / 64.0
+            insts = per_stage * units / 64.0 * (T - 1) / T      # a wavefront walks T - 1 stages (tools/pmc_sq.py divides by them)
             floor_ms = insts / (1024 * 2.4e9 / 4) * 1e3
             return {"valu_insts_per_launch": insts, "issue_ms_at_2.4GHz": floor_ms, "frac": floor_ms / dom["avg_ms"],
                     "wavefront_cycles_issuing_valu": issuing, "wavefronts_per_simd": 2,
@@ -728,7 +728,7 @@ def run(a):
                      if overlap else "the timed region",
                      # the same kernel against the other roof it touches: vector instructions per wavefront-stage from
                      # the SQ counters of the committed one-stream run, priced at the nominal issue rate
-                     "vector_issue": vector_issue(dom, units)},
+                     "vector_issue": vector_issue(dom, units, T)},
         "kernels": kernels,
         "attribution_ms_per_step": float(ms.sum(1).mean()),
         # whole iteration, per GPU: SURVEY 8d's 496 B per trajectory-stage over the wall time of a step

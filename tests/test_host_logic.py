@@ -102,6 +102,18 @@ def test_two_rank_gloo_reduction_equals_single_process(tmp_path):
     assert r0[3] == B and r0[4] == 1
 
 
+def test_vector_issue_of_the_bench_line():
+    """roofline.vector_issue: the dominant kernel priced against the fp64 issue roof from the committed SQ counters
+    (profiles/r05_sq_counters.txt: 624.2 vector instructions per wavefront and stage of the large-batch forward pass)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    units = 131072 * 500
+    v = bench.vector_issue({"kernel": "k_forward<true, false, 2, true, float>", "avg_ms": 1.8}, units, 500)
+    assert v["valu_insts_per_launch"] == pytest.approx(6.379e8, rel=2e-4)          # the counter's own per-launch figure
+    assert v["issue_ms_at_2.4GHz"] == pytest.approx(1.038, abs=1e-3) and v["frac"] == pytest.approx(0.577, abs=1e-3)
+    assert bench.vector_issue({"kernel": "k_forward_split<true, false, float, 1>", "avg_ms": 0.3}, units, 500) is None
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     """bench.py --gpus N must run N ranks: under a launcher with another WORLD_SIZE it exits non-zero instead of
     printing a line for the wrong rank count (no GPU is touched before that check)."""
