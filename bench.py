@@ -696,7 +696,9 @@ def run(a):
         kernels.append(entry("backward", kernel_names(s.nt, True), full, "full Hessian, kk > %d" % prm.hessian_switch))
     for pname in passes[1:]:   # the other passes do not change with the Hessian
         kernels.append(entry(pname, kernel_names(s.nt, False), np.ones(K, bool), "all"))
-    dom = max((e for e in kernels if "algorithmic_bytes" in e), key=lambda e: e["avg_ms"])
+    # the dominant kernel: the one the iterations spend most time in (launches x average; by average alone the entry flipped
+    # between the forward pass and the 11-launch full-Hessian backward pass from box to box, 1.79 against 1.77-1.81 ms)
+    dom = max((e for e in kernels if "algorithmic_bytes" in e), key=lambda e: e["avg_ms"] * e["launches"])
     fin_b = int(summ[3].item() - summ[4].item())
     out = {
         "metric": "Newton iters/sec (whole node), batched 6-state T=%d trajectories; fp64 rel-err" % T,
